@@ -1,0 +1,219 @@
+// attention_bf16.hip - softmax(q k^T / sqrt(64) [causal]) v for head_dim 64, flash-style on MFMA.
+// (reference: F.scaled_dot_product_attention at pytorch_models/transformer.py:52; the head
+//  split / merge of transformer.py:47-53 is folded into the addressing.)
+//
+// Roofline: MFMA-bound for long sequences (4*Lq*Lk*64 flop per head against (Lq + 2*Lk)*128 B... read once
+// per 128-query block); at L = 197 it is a small kernel whose K/V (25 KB per head) live in L2.
+//
+// Workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.  K/V tiles of
+// 64 keys are register-staged into a double-buffered LDS image (one barrier per tile).
+//   S^T = K Q^T   : MFMA 32x32x16, A = K rows from LDS (ds_read_b128, XOR-swizzled), B = Q (registers).
+//                   The accumulator then has the QUERY on the lane and 32 of the tile's 64 keys in
+//                   registers (the other 32 sit in lane ^ 32): the row max / sum are in-lane + one swap.
+//   O^T = V^T P^T : the S^T accumulator, converted to bf16 in place, IS the B operand (k = key); the
+//                   A operand V^T comes from the row-major V image through ds_read_b64_tr_b16.
+//                   O^T again has the query on the lane, so the online-softmax rescale is per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+constexpr int TILE_B = KV_TILE * 128;  // 8 KiB: 64 rows x 64 bf16
+
+__device__ __forceinline__ bf16x8 tr_read_pair(const char* p0, const char* p1) {
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PM_LDS s16x4*)p0);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PM_LDS s16x4*)p1);
+  return u.v;
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q, int64_t qsb, int64_t qst,
+                                                     const bf16* __restrict__ K, int64_t ksb, int64_t kst,
+                                                     const bf16* __restrict__ V, int64_t vsb, int64_t vst,
+                                                     bf16* __restrict__ O, int64_t osb, int64_t ost, int H, int Lq,
+                                                     int Lk, int nqb) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K, V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = wg % nqb, bh = wg / nqb;
+  const int h = bh % H, b = bh / H;
+  const int q0 = qb * 128;
+  const int r = lane & 31, hh = lane >> 5;
+
+  const bf16* Qp = Q + (int64_t)b * qsb + h * 64;
+  const bf16* Kp = K + (int64_t)b * ksb + h * 64;
+  const bf16* Vp = V + (int64_t)b * vsb + h * 64;
+
+  // this lane's query row (clamped for loads; masked at the store)
+  const int qi = q0 + wave * 32 + r;
+  const int qi_ld = qi < Lq ? qi : Lq - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qp + (int64_t)qi_ld * qst + s * 16 + hh * 8);
+
+  int nT = (Lk + KV_TILE - 1) / KV_TILE;
+  if (CAUSAL) {
+    int qlast = q0 + 127;
+    if (qlast > Lq - 1) qlast = Lq - 1;
+    const int tl = qlast / KV_TILE + 1;  // tiles holding any key <= the block's last query
+    if (tl < nT) nT = tl;
+  }
+
+  // register staging: thread t moves chunks (t, t + 256) of the 64 x 8 chunk grid of K and of V
+  const int srow0 = tid >> 3, sch = tid & 7;
+  bf16x8 kreg[2], vreg[2];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = t * KV_TILE + srow0 + i * 32;
+      key = key < Lk ? key : Lk - 1;
+      kreg[i] = *(const bf16x8*)(Kp + (int64_t)key * kst + sch * 8);
+      vreg[i] = *(const bf16x8*)(Vp + (int64_t)key * vst + sch * 8);
+    }
+  };
+  auto write_tile = [&](char* kbuf) {
+    char* vbuf = kbuf + TILE_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow0 + i * 32;
+      *(bf16x8*)(kbuf + row * 128 + swz_pos(row, sch) * 16) = kreg[i];
+      *(bf16x8*)(vbuf + row * 128 + ((sch ^ (((row >> 1) & 1) << 2)) * 16)) = vreg[i];
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+
+  // tr-read lane geometry (see header): 16-lane group g, lane-in-group i = 4*qq + pp
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+
+  load_tile(0);
+  write_tile(smem);
+  __syncthreads();
+
+  for (int t = 0; t < nT; ++t) {
+    const char* kbuf = smem + (t & 1) * 2 * TILE_B;
+    const char* vbuf = kbuf + TILE_B;
+    if (t + 1 < nT) load_tile(t + 1);
+
+    // ---- S^T = K Q^T : two 32-key blocks
+    f32x16 sc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+      const int row = kb * 32 + r;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(kbuf + row * 128 + swz_pos(row, 2 * s + hh) * 16);
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- masks (key tail / causal), scale into the log2 domain
+    const int key_base = t * KV_TILE + 4 * hh;
+    const bool tail = (t + 1) * KV_TILE > Lk;
+    const bool diag = CAUSAL && ((t + 1) * KV_TILE - 1 > q0 + wave * 32);
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float v = sc[kb][i] * c;
+        if (tail || diag) {
+          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);
+          if (key >= Lk || (CAUSAL && key > qi)) v = -1e30f;
+        }
+        sc[kb][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(sc[kb][i] - m_new);
+        sc[kb][i] = p;
+        ps += p;
+      }
+    l_run = fmaf(l_run, alpha, ps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sc[kb][8 * s + j];
+        const int row = kb * 32 + 16 * s + 4 * (g >> 1) + qq;
+        const int flip = ((row >> 1) & 1) << 2;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int ch = db * 4 + 2 * (g & 1) + (pp >> 1);
+          const char* p0 = vbuf + row * 128 + ((ch ^ flip) * 16) + (pp & 1) * 8;
+          const bf16x8 vf = tr_read_pair(p0, p0 + 8 * 128);
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+        }
+      }
+
+    if (t + 1 < nT) write_tile(smem + ((t + 1) & 1) * 2 * TILE_B);
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qi < Lq) {
+    bf16* op = O + (int64_t)b * osb + (int64_t)qi * ost + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * gq + j] * inv);
+        *(bf16x4*)(op + db * 32 + 8 * gq + 4 * hh) = o;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int pm_attention_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k,
+                                 int64_t k_stride_b, int64_t k_stride_t, const void* v, int64_t v_stride_b,
+                                 int64_t v_stride_t, void* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
+                                 int64_t H, int64_t Lq, int64_t Lk, int causal, void* stream) {
+  if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0) return PM_EINVAL;
+  if (B == 0 || Lq == 0) return PM_OK;
+  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 8) return PM_EALIGN;
+  if ((o_stride_t | o_stride_b) % 4) return PM_EALIGN;
+  if (q_stride_t < H * 64 || k_stride_t < H * 64 || v_stride_t < H * 64 || o_stride_t < H * 64) return PM_EINVAL;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return PM_EALIGN;
+  if ((uintptr_t)o & 7) return PM_EALIGN;
+  if (Lq > (1 << 24) || Lk > (1 << 24)) return PM_EINVAL;
+  const int nqb = (int)((Lq + 127) / 128);
+  const int64_t nblk = B * H * nqb;
+  if (nblk > 0x7fffffff) return PM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (causal)
+    hipLaunchKernelGGL((attn_fwd_hd64<true>), dim3((unsigned)nblk), dim3(256), 0, st, (const bf16*)q, q_stride_b,
+                       q_stride_t, (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t,
+                       (bf16*)o, o_stride_b, o_stride_t, (int)H, (int)Lq, (int)Lk, nqb);
+  else
+    hipLaunchKernelGGL((attn_fwd_hd64<false>), dim3((unsigned)nblk), dim3(256), 0, st, (const bf16*)q, q_stride_b,
+                       q_stride_t, (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t,
+                       (bf16*)o, o_stride_b, o_stride_t, (int)H, (int)Lq, (int)Lk, nqb);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}

@@ -1,0 +1,86 @@
+// common.h - shared device helpers for the gfx950 kernels of libpm_mi355x.so.
+// CDNA4 only: 64-wide wavefronts, MFMA 16x16x32 / 32x32x16 bf16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pm_mi355x.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define PM_LDS __attribute__((address_space(3)))
+#define PM_GLOBAL __attribute__((address_space(1)))
+
+#define PM_CHECK_LAUNCH()                                  \
+  do {                                                     \
+    if (hipGetLastError() != hipSuccess) return PM_ELAUNCH; \
+  } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// async global -> LDS copy of 16 B per lane; the LDS destination is wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const PM_GLOBAL void*)gsrc, (PM_LDS void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one rcp, one exp, five fma.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
+}
+
+// activation table of MLP (pytorch_models/transformer.py:60-65); PRECISE selects libm erff/tanhf.
+template <int ACT, bool PRECISE>
+__device__ __forceinline__ float apply_act(float x) {
+  if constexpr (ACT == PM_ACT_GELU) {
+    const float e = PRECISE ? erff(x * 0.70710678118654752f) : erf_fast(x * 0.70710678118654752f);
+    return 0.5f * x * (1.0f + e);
+  } else if constexpr (ACT == PM_ACT_GELU_TANH) {
+    const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+    return 0.5f * x * (1.0f + tanhf(u));
+  } else if constexpr (ACT == PM_ACT_RELU) {
+    return fmaxf(x, 0.0f);
+  } else if constexpr (ACT == PM_ACT_SILU) {
+    return x / (1.0f + __expf(-x));
+  } else {
+    return x;
+  }
+}
+
+// Workgroup-id remap so that each XCD (blocks b, b+8, b+16, ... share one) walks a CONTIGUOUS range
+// of tile ids: neighbouring tiles then hit the same per-XCD L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// LDS tile with 128-byte rows (64 bf16) in 16-byte chunks; chunk c of row r lives at position
+// c ^ ((r >> 1) & 7): conflict-free for ds_read_b128 fragment reads of both the 16-row x 4-chunk
+// (MFMA 16x16x32) and 32-row x 2-chunk (MFMA 32x32x16) shapes.
+__device__ __forceinline__ int swz_pos(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

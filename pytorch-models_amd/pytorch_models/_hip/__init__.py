@@ -1,0 +1,64 @@
+"""ctypes binding of libpm_mi355x.so (include/pm_mi355x.h).
+
+The library is the product: there is NO fallback.  ``lib()`` raises if the shared object is
+missing, and every ``ops.*`` wrapper raises ``RuntimeError`` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))  # .../pytorch-models_amd
+LIB_PATH = os.path.join(REPO_PKG_ROOT, "csrc", "build", "libpm_mi355x.so")
+HEADER_PATH = os.path.join(os.path.dirname(REPO_PKG_ROOT), "include", "pm_mi355x.h")
+
+PM_BF16, PM_F32 = 0, 1
+ACT = dict(none=0, gelu=1, approximate_gelu=2, relu=3, silu=4)
+
+_p, _i, _l, _f = c_void_p, c_int, c_int64, c_float
+# name -> argtypes; must list every function declared in include/pm_mi355x.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "pm_abi_version": ([], c_int),
+    "pm_strerror": ([_i], c_char_p),
+    "pm_linear_bf16": ([_p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
+    "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
+    "pm_attention_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
+    "pm_vit_tokens": ([_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
+}
+
+_lib = None
+
+
+def header_functions() -> list[str]:
+    """Names of the functions include/pm_mi355x.h declares."""
+    src = open(HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+                "(run `make -C pytorch-models_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "This package has no CPU or eager fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if L.pm_abi_version() != 1:
+            raise RuntimeError(f"libpm_mi355x ABI {L.pm_abi_version()} != binding ABI 1: rebuild the library")
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what}: pm_mi355x error {code}: {lib().pm_strerror(code).decode()}")

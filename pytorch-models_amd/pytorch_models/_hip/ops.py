@@ -1,0 +1,112 @@
+"""Tensor-level wrappers over the C ABI: validate on the host, pass raw device pointers and the
+current torch stream, raise on a non-zero status.  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import ACT, PM_BF16, PM_F32, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return PM_BF16
+    if t.dtype == torch.float32:
+        return PM_F32
+    raise TypeError(f"pm_mi355x kernels take bf16 / f32 tensors, got {t.dtype}")
+
+
+def _need(cond: bool, msg: str) -> None:
+    if not cond:
+        raise ValueError(msg)
+
+
+def _cuda(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "pytorch_models (MI355X build) runs on HIP devices only: got a tensor on "
+                f"{t.device}. There is no CPU path; move the module and its inputs to 'cuda'."
+            )
+
+
+def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none", resid: Tensor | None = None,
+           out_dtype: torch.dtype = torch.bfloat16, out: Tensor | None = None) -> Tensor:
+    """y = act(x @ w.T + bias) + resid.  x (M, K) bf16, w (N, K) bf16, bias f32 (N), resid (M, N) bf16|f32."""
+    _cuda(x, w, bias, resid, out)
+    _need(x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1], f"linear: x {tuple(x.shape)} vs w {tuple(w.shape)}")
+    _need(x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16, "linear: x and w must be bf16")
+    _need(x.stride(1) == 1 and w.stride(1) == 1, "linear: x and w must be K-contiguous")
+    M, K = x.shape
+    N = w.shape[0]
+    if bias is not None:
+        _need(bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N, "linear: bias must be f32 (N)")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    _need(out.shape == (M, N) and out.stride(1) == 1, "linear: bad out")
+    if resid is not None:
+        _need(resid.shape == (M, N) and resid.stride(1) == 1, "linear: resid must be (M, N), row-major")
+    rc = lib().pm_linear_bf16(
+        x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
+        resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
+        _dt(resid) if resid is not None else 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream())
+    check(rc, f"pm_linear_bf16(M={M}, N={N}, K={K})")
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype | None = None) -> Tensor:
+    """Row-wise LayerNorm of x (M, d) (bf16 | f32) with f32 gamma / beta."""
+    _cuda(x, gamma, beta)
+    _need(x.dim() == 2 and x.stride(1) == 1, "layernorm: x must be (M, d), row-major")
+    M, d = x.shape
+    _need(gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == d and beta.numel() == d,
+          "layernorm: gamma / beta must be f32 (d)")
+    out = torch.empty((M, d), dtype=out_dtype or x.dtype, device=x.device)
+    rc = lib().pm_layernorm(x.data_ptr(), x.stride(0), _dt(x), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                            out.data_ptr(), out.stride(0), _dt(out), M, d, _stream())
+    check(rc, f"pm_layernorm(M={M}, d={d})")
+    return out
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = False) -> Tensor:
+    """q (B, Lq, H*64), k / v (B, Lk, H*64) bf16 views with unit last stride (e.g. column slices of a packed
+    QKV projection) -> (B, Lq, H*64) bf16, heads already merged."""
+    _cuda(q, k, v)
+    _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention: operands must be (B, L, H*64)")
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    _need(D == n_heads * 64 and k.shape == (B, Lk, D) and v.shape == (B, Lk, D), "attention: shape mismatch / head_dim != 64")
+    for t in (q, k, v):
+        _need(t.dtype == torch.bfloat16 and t.stride(2) == 1, "attention: bf16 operands with unit last stride")
+    out = torch.empty((B, Lq, D), dtype=torch.bfloat16, device=q.device)
+    rc = lib().pm_attention_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                 v.data_ptr(), v.stride(0), v.stride(1), out.data_ptr(), out.stride(0), out.stride(1),
+                                 B, n_heads, Lq, Lk, int(causal), _stream())
+    check(rc, f"pm_attention_bf16(B={B}, H={n_heads}, Lq={Lq}, Lk={Lk})")
+    return out
+
+
+def vit_tokens(imgs: Tensor, w2d: Tensor, bias: Tensor, pe: Tensor, cls: Tensor | None, patch: int) -> Tensor:
+    """imgs f32 (N, 3, H, W) -> tokens bf16 (N, L [+1], d): patch projection + pe (+ cls row)."""
+    _cuda(imgs, w2d, bias, pe, cls)
+    _need(imgs.dim() == 4 and imgs.shape[1] == 3 and imgs.dtype == torch.float32 and imgs.is_contiguous(),
+          "vit_tokens: imgs must be contiguous f32 (N, 3, H, W)")
+    N, _, H, W = imgs.shape
+    d = w2d.shape[0]
+    L = (H // patch) * (W // patch)
+    _need(w2d.dtype == torch.bfloat16 and w2d.is_contiguous() and w2d.shape == (d, 3 * patch * patch), "vit_tokens: bad weight")
+    _need(bias.dtype == torch.float32 and bias.numel() == d and bias.is_contiguous(), "vit_tokens: bias f32 (d)")
+    _need(pe.dtype == torch.float32 and pe.numel() == L * d and pe.is_contiguous(),
+          f"vit_tokens: pe must hold {L} x {d} f32 values (image {H}x{W}, patch {patch}); call resize_pe first")
+    if cls is not None:
+        _need(cls.dtype == torch.float32 and cls.numel() == d and cls.is_contiguous(), "vit_tokens: cls f32 (d)")
+    out = torch.empty((N, L + (cls is not None), d), dtype=torch.bfloat16, device=imgs.device)
+    rc = lib().pm_vit_tokens(imgs.data_ptr(), w2d.data_ptr(), bias.data_ptr(), pe.data_ptr(),
+                             cls.data_ptr() if cls is not None else None, out.data_ptr(), N, H, W, patch, d, _stream())
+    check(rc, f"pm_vit_tokens(N={N}, H={H}, W={W}, P={patch}, d={d})")
+    return out

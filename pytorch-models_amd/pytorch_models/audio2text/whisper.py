@@ -1,0 +1,121 @@
+"""Whisper on MI355X, drop-in for /root/reference pytorch_models/audio2text/whisper.py
+(WhisperEncoder, WhisperDecoder, Whisper, WhisperPreprocessor, Whisper.from_openai; same parameter
+names: stem.0 / stem.2, pos_embs, layers, norm, token_embs).
+
+New capability (absent in the reference, README.md:86): ``Whisper.generate`` - batched greedy decoding
+with a KV cache, see generate.py.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from .._hip import ops
+from ..audio.spectrogram import MelSpectrogram
+from ..transformer import Decoder, Encoder, LayerNorm, _f32, derived
+
+_SIZES = {  # tag -> (n_layers, d_model); "base" is 8 layers exactly as the reference builds it
+    "tiny": (4, 384), "tiny.en": (4, 384), "base": (8, 512), "base.en": (8, 512),
+    "small": (12, 768), "small.en": (12, 768), "medium": (24, 1024), "medium.en": (24, 1024),
+    "large-v1": (32, 1280), "large-v2": (32, 1280), "large-v3": (32, 1280),
+}
+
+
+class WhisperEncoder(nn.Module):
+    max_seq_len = 3000
+
+    def __init__(self, n_layers: int, d_model: int, n_mels: int = 80, dropout: float = 0.0) -> None:
+        super().__init__()
+        self.stem = nn.Sequential(
+            nn.Conv1d(n_mels, d_model, 3, 1, 1),
+            nn.GELU(),
+            nn.Conv1d(d_model, d_model, 3, 2, 1),
+            nn.GELU(),
+        )
+        self.register_buffer("pos_embs", torch.zeros(self.max_seq_len // 2, d_model))
+        self.pos_embs: Tensor
+        self.layers = Encoder(n_layers, d_model, dropout=dropout)
+        self.norm = LayerNorm(d_model)
+
+    def _stem_weights(self):
+        c1, c2 = self.stem[0], self.stem[2]
+
+        def build():
+            d, n_mels, _ = c1.weight.shape
+            cpad = (n_mels + 63) // 64 * 64
+            w1 = torch.zeros(d, 3, cpad, dtype=torch.bfloat16, device=c1.weight.device)  # (out, tap, channel) K-major
+            w1[:, :, :n_mels] = c1.weight.detach().permute(0, 2, 1).to(torch.bfloat16)
+            w2 = c2.weight.detach().permute(0, 2, 1).contiguous().view(d, 3 * d).to(torch.bfloat16)
+            return w1.view(d, 3 * cpad), c1.bias.detach().float().contiguous(), w2, c2.bias.detach().float().contiguous()
+
+        return derived(self, "stem", (c1.weight, c1.bias, c2.weight, c2.bias), build)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """(B, n_mels, T) -> (B, T // 2, d): conv stem (both convs as MFMA GEMMs with fused GELU, the second
+        also adding pos_embs in its epilogue), Encoder, LayerNorm."""
+        if self.stem[0].weight.dtype != torch.bfloat16:
+            raise NotImplementedError("WhisperEncoder: only the bf16 path is built; use model.to(torch.bfloat16)")
+        w1, b1, w2, b2 = self._stem_weights()
+        B, _, T = x.shape
+        d = w2.shape[0]
+        y1 = ops.whisper_stem1(x.float().contiguous(), w1, b1)  # (B, T + 2, d) bf16, rows 0 and T + 1 zero
+        L = (T - 1) // 2 + 1
+        pos = _f32(self, "pos", self.pos_embs)[:L]
+        y2 = ops.linear(y1.view(B * (T + 2), d), w2, b2, act="gelu", resid=pos, resid_period=L,
+                        x_rows_per_batch=L, x_batch_stride=(T + 2) * d, x_row_stride=2 * d, k=3 * d, m=B * L)
+        return self.norm(self.layers(y2.view(B, L, d)))
+
+
+class WhisperDecoder(nn.Module):
+    max_seq_len = 448
+
+    def __init__(self, vocab_size: int, n_layers: int, d_model: int, dropout: float = 0.0) -> None:
+        super().__init__()
+        self.token_embs = nn.Embedding(vocab_size, d_model)
+        self.pos_embs = nn.Parameter(torch.zeros(self.max_seq_len, d_model))
+        self.layers = Decoder(n_layers, d_model, cross_attn=True, dropout=dropout)
+        self.norm = LayerNorm(d_model)
+
+    def forward(self, x: Tensor, memory: Tensor) -> Tensor:
+        """tokens (B, L) int64, memory (B, S, d) -> logits (B, L, V) (tied embeddings), teacher-forced."""
+        E = self.token_embs.weight
+        if E.dtype != torch.bfloat16:
+            raise NotImplementedError("WhisperDecoder: only the bf16 path is built; use model.to(torch.bfloat16)")
+        h = ops.embed_tokens(x, E, _f32(self, "pos", self.pos_embs))  # (B, L, d) bf16
+        h = self.norm(self.layers(h, memory))
+        return ops.logits(h.view(-1, h.shape[-1]), E).view(*x.shape, E.shape[0])
+
+
+class Whisper(nn.Module):
+    def __init__(self, vocab_size: int, n_layers: int, d_model: int, n_mels: int = 80, dropout: float = 0.0) -> None:
+        super().__init__()
+        self.encoder = WhisperEncoder(n_layers, d_model, n_mels, dropout=dropout)
+        self.decoder = WhisperDecoder(vocab_size, n_layers, d_model, dropout=dropout)
+
+    def forward(self, x: Tensor, targets: Tensor) -> Tensor:
+        return self.decoder(targets, self.encoder(x))
+
+    @staticmethod
+    def from_openai(model_tag: str, *, pretrained: bool = False, **kwargs) -> "Whisper":
+        n_layers, d_model = _SIZES[model_tag]
+        if model_tag == "large-v3":
+            n_mels, vocab_size = 128, 51866
+        else:
+            n_mels, vocab_size = 80, (51864 if model_tag.endswith(".en") else 51865)
+        m = Whisper(vocab_size, n_layers, d_model, n_mels, **kwargs)
+        if pretrained:
+            raise NotImplementedError(
+                "Whisper.from_openai(pretrained=True) needs a network download, which this build does not do; "
+                "construct with pretrained=False and load a local checkpoint into the (reference-named) parameters.")
+        return m
+
+
+class WhisperPreprocessor(MelSpectrogram):
+    def __init__(self, variant: str = "tiny") -> None:
+        n_mels = 128 if variant == "large-v3" else 80
+        super().__init__(400, 160, n_mels, 16_000)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """(..., T) waveform -> (..., n_mels, T // 160) log-mel: last frame dropped, log10, floored at the
+        PER-SAMPLE max - 8, (x + 4) / 4 - all inside the two logmel kernels."""
+        return ops.whisper_logmel(x, self.window, self.filters)

@@ -1,0 +1,140 @@
+"""ViT on MI355X, drop-in for /root/reference pytorch_models/image/vit.py (ViT, from_google,
+from_facebook, resize_pe; same parameter names: patch_embed, cls_token, pe, layers, norm, pooler.*).
+
+forward = pm_vit_tokens (im2col-free patch projection + pe + cls in one kernel) -> Encoder
+(transformer.py) -> final LayerNorm -> pooler.  Unlike the reference, batch > 1 works with a cls
+token: the cls row is broadcast over the batch, i.e. the result is the stack of the reference's
+batch-1 results (the reference's torch.cat raises there - vit.py:80-81).
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .._hip import ops
+from ..transformer import MHA, MLP, Encoder, LayerNorm, _f32, _fused_mlp, derived
+
+
+class ClassTokenPooling(nn.Module):
+    def forward(self, x: Tensor) -> Tensor:
+        return x[:, 0]
+
+
+class GlobalAveragePooling(nn.Module):
+    def forward(self, x: Tensor) -> Tensor:
+        return x.mean(1)
+
+
+class MHAPooling(nn.Module):
+    """MAP head (siglip): a learned probe attends over all tokens, then x + mlp(norm(x)) - vit.py:30-43."""
+
+    def __init__(self, d_model: int, n_heads: int, bias: bool = True, mlp_ratio: float = 4.0, norm_eps: float = 1e-6) -> None:
+        super().__init__()
+        self.probe = nn.Parameter(torch.zeros(1, 1, d_model))
+        self.attn = MHA(d_model, n_heads=n_heads, bias=bias)
+        self.norm = LayerNorm(d_model, norm_eps)
+        self.mlp = MLP(d_model, int(d_model * mlp_ratio))
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.attn(self.probe, x).squeeze(1)
+        return _fused_mlp(self.mlp, self.norm(x), x)
+
+
+_SIZES = dict(Ti=(12, 192, 3), S=(12, 384, 6), M=(12, 512, 8), B=(12, 768, 12), L=(24, 1024, 16), H=(32, 1280, 16))
+
+
+class ViT(nn.Module):
+    norm_eps = 1e-6
+
+    def __init__(
+        self,
+        n_layers: int,
+        d_model: int,
+        n_heads: int,
+        patch_size: int,
+        img_size: int = 224,
+        cls_token: bool = True,
+        pool_type: str = "cls_token",
+        dropout: float = 0.0,
+    ) -> None:
+        assert img_size % patch_size == 0
+        super().__init__()
+        self.patch_embed = nn.Conv2d(3, d_model, patch_size, patch_size)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, d_model)) if cls_token else None
+        self.pe = nn.Parameter(torch.zeros(1, (img_size // patch_size) ** 2, d_model))
+        self.layers = Encoder(n_layers, d_model, n_heads=n_heads, dropout=dropout, norm_eps=self.norm_eps)
+        self.norm = LayerNorm(d_model, self.norm_eps)
+        poolers = dict(
+            cls_token=ClassTokenPooling,
+            gap=GlobalAveragePooling,
+            mha=partial(MHAPooling, d_model, n_heads, norm_eps=self.norm_eps),
+        )
+        self.pooler = poolers[pool_type]()
+
+    def tokens(self, imgs: Tensor) -> Tensor:
+        """(N, 3, H, W) f32 -> (N, L [+1], d) bf16: patch projection + pe (+ cls) in one kernel."""
+        pw = self.patch_embed.weight
+        if pw.dtype != torch.bfloat16:
+            raise NotImplementedError(f"ViT: only the bf16 path is built (weights are {pw.dtype}); use model.to(torch.bfloat16)")
+        w2d = pw.view(pw.shape[0], -1)
+        cls = None if self.cls_token is None else _f32(self, "cls", self.cls_token).view(-1)
+        return ops.vit_tokens(imgs.float().contiguous(), w2d, _f32(self, "pb", self.patch_embed.bias),
+                              _f32(self, "pe", self.pe).view(-1, pw.shape[0]), cls, pw.shape[2])
+
+    def forward(self, imgs: Tensor) -> Tensor:
+        out = self.layers(self.tokens(imgs))
+        if isinstance(self.pooler, ClassTokenPooling):
+            # LayerNorm is row-wise, so normalising only the pooled row equals norm-then-pool (vit.py:83-84)
+            return self.norm(out[:, 0])
+        return self.pooler(self.norm(out))
+
+    @torch.no_grad()
+    def resize_pe(self, size: int, interpolation_mode: str = "bicubic") -> None:
+        """Interpolate the (g, g) grid of position vectors to the grid of a ``size`` x ``size`` image."""
+        g_old = int(self.pe.shape[1] ** 0.5)
+        g_new = size // self.patch_embed.weight.shape[2]
+        grid = self.pe.float().unflatten(1, (g_old, g_old)).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, (g_new, g_new), mode=interpolation_mode)
+        self.pe = nn.Parameter(grid.permute(0, 2, 3, 1).flatten(1, 2).to(self.pe.dtype))
+
+    @staticmethod
+    def _parse(model_tag: str, default_weights: str):
+        tag, weights = model_tag.split("_") if "_" in model_tag else (model_tag, default_weights)
+        size, patch = tag.split("/")
+        return tag, weights, _SIZES[size], int(patch)
+
+    @staticmethod
+    def from_google(model_tag: str, *, pretrained: bool = False, **kwargs) -> "ViT":
+        """"Ti/16", "B/16_augreg", "B/16_siglip", ... (default weights: augreg); siglip => no cls token, MAP pooling."""
+        _, weights, (n_layers, d_model, n_heads), patch = ViT._parse(model_tag, "augreg")
+        extra = dict(cls_token=False, pool_type="mha") if weights == "siglip" else {}
+        m = ViT(n_layers, d_model, n_heads, patch, **extra, **kwargs)
+        if pretrained:
+            if weights not in ("augreg", "siglip"):
+                raise ValueError(f"Unsupported weights={weights}")
+            _no_download("ViT.from_google")
+        return m
+
+    @staticmethod
+    def from_facebook(model_tag: str, *, pretrained: bool = False, **kwargs) -> "ViT":
+        """"S/16_deit3" (default), "S/16_dino", "S/14_dinov2" (default img_size 518)."""
+        _, weights, (n_layers, d_model, n_heads), patch = ViT._parse(model_tag, "deit3")
+        if weights in ("deit3", "dino"):
+            kwargs.setdefault("img_size", 224)
+        elif weights == "dinov2":
+            kwargs.setdefault("img_size", 518)
+        else:
+            raise ValueError(f"Unsupported {weights}")
+        m = ViT(n_layers, d_model, n_heads, patch, **kwargs)
+        if pretrained:
+            _no_download("ViT.from_facebook")
+        return m
+
+
+def _no_download(who: str):
+    raise NotImplementedError(
+        f"{who}(pretrained=True) needs a network download, which this build does not do; construct with "
+        "pretrained=False and load a local checkpoint into the (reference-named) parameters.")

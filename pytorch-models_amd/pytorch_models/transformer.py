@@ -1,0 +1,313 @@
+"""Shared transformer blocks on MI355X: MHA, MLP, LayerNorm, Encoder/Decoder layers and stacks.
+
+Drop-in for /root/reference pytorch_models/transformer.py (same class names, constructor and
+forward signatures, child-module and parameter names - the weight converters index them), but the
+forward is a short sequence of hand-written gfx950 kernels reached through the C ABI of
+``libpm_mi355x.so``:
+
+    LayerNorm            -> pm_layernorm            (wave-per-row, fp32 statistics)
+    q/k/v projections    -> ONE pm_linear_bf16 over the concatenated weight (packed lazily)
+    SDPA                 -> pm_attention_bf16, reading the packed projection in place
+    out_proj + residual  -> pm_linear_bf16 with the residual add in its epilogue
+    linear1 + GELU       -> pm_linear_bf16 with the activation in its epilogue
+    linear2 + residual   -> pm_linear_bf16 with the residual add in its epilogue
+
+There is no CPU or eager fallback: tensors must live on a HIP device and the modules must be cast to
+bfloat16 (``model.to(torch.bfloat16).cuda()``); anything the kernels do not cover raises.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from ._hip import ops
+
+_ACTS = {
+    "gelu": lambda: nn.GELU(),
+    "approximate_gelu": lambda: nn.GELU(approximate="tanh"),
+    "relu": lambda: nn.ReLU(inplace=True),
+    "silu": lambda: nn.SiLU(),
+}
+
+
+def _sig(ts) -> tuple:
+    return tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ts if t is not None)
+
+
+def derived(module: nn.Module, key: str, params, build):
+    """Value derived from parameters (packed / re-typed weights), rebuilt when any of them changes
+    (in-place ``copy_`` bumps ``_version``; ``.to()`` moves storage)."""
+    store = module.__dict__.setdefault("_pm_derived", {})
+    sig = _sig(params)
+    hit = store.get(key)
+    if hit is None or hit[0] != sig:
+        with torch.no_grad():
+            hit = (sig, build())
+        store[key] = hit
+    return hit[1]
+
+
+def _f32(module: nn.Module, key: str, t: Tensor | None) -> Tensor | None:
+    if t is None:
+        return None
+    return derived(module, key, (t,), lambda: t.detach().float().contiguous())
+
+
+def _require_bf16(x: Tensor, w: Tensor, who: str) -> None:
+    if not x.is_cuda or not w.is_cuda:
+        raise RuntimeError(
+            f"{who}: the MI355X build of pytorch_models runs on HIP devices only (input on {x.device}, weights on "
+            f"{w.device}); there is no CPU path.")
+    if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+        raise NotImplementedError(
+            f"{who}: only the bf16 path is built (weights {w.dtype}, input {x.dtype}); use model.to(torch.bfloat16)")
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm whose forward is pm_layernorm (parameter names unchanged)."""
+
+    def forward(self, x: Tensor, out_dtype: torch.dtype | None = None) -> Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("LayerNorm: HIP devices only (no CPU path)")
+        g = _f32(self, "g", self.weight)
+        b = _f32(self, "b", self.bias)
+        y = ops.layernorm(x.reshape(-1, x.shape[-1]), g, b, self.eps, out_dtype)
+        return y.view(*x.shape)
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose forward is pm_linear_bf16 (parameter names unchanged)."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        _require_bf16(x, self.weight, "Linear")
+        y = ops.linear(x.reshape(-1, x.shape[-1]), self.weight, _f32(self, "b", self.bias))
+        return y.view(*x.shape[:-1], self.out_features)
+
+
+class MHA(nn.Module):
+    def __init__(
+        self,
+        d_model: int,
+        n_heads: int | None = None,
+        head_dim: int | None = None,
+        bias: bool = True,
+        dropout: float = 0.0,
+    ) -> None:
+        # same resolution order as the reference (transformer.py:18-26): default head_dim 64
+        if n_heads is None and head_dim is None:
+            head_dim = 64
+        if head_dim is None:
+            head_dim = d_model // n_heads
+        if n_heads is None:
+            n_heads = d_model // head_dim
+        super().__init__()
+        inner = n_heads * head_dim
+        self.q_proj = Linear(d_model, inner, bias)
+        self.k_proj = Linear(d_model, inner, bias)
+        self.v_proj = Linear(d_model, inner, bias)
+        self.out_proj = Linear(inner, d_model, bias)
+        self.n_heads = n_heads
+        self.head_dim = head_dim
+        self.dropout = dropout
+
+    # ---- packed projection weights (derived lazily from the four nn.Linear)
+    def _pack(self, names: str):
+        mods = [getattr(self, f"{n}_proj") for n in names]
+        params = [m.weight for m in mods] + [m.bias for m in mods]
+
+        def build():
+            w = torch.cat([m.weight.detach() for m in mods], 0).contiguous()
+            b = None if mods[0].bias is None else torch.cat([m.bias.detach().float() for m in mods], 0).contiguous()
+            return w, b
+
+        return derived(self, "pack_" + names, params, build)
+
+    def forward(
+        self,
+        q: Tensor,
+        k: Tensor | None = None,
+        v: Tensor | None = None,
+        attn_bias: Tensor | None = None,
+        causal: bool = False,
+    ) -> Tensor:
+        return self.attend(q, k, v, attn_bias, causal)
+
+    def attend(self, q, k=None, v=None, attn_bias=None, causal=False, residual: Tensor | None = None) -> Tensor:
+        """forward() plus an optional residual that is added inside the out_proj kernel's epilogue."""
+        _require_bf16(q, self.q_proj.weight, "MHA")
+        if attn_bias is not None:
+            raise NotImplementedError("MHA: attn_bias is not covered by the gfx950 attention kernel yet")
+        if self.head_dim != 64:
+            raise NotImplementedError(f"MHA: head_dim {self.head_dim} != 64 is not covered by the gfx950 attention kernel")
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("MHA: inference only (attention dropout is not implemented)")
+        H, inner = self.n_heads, self.n_heads * 64
+        Lq = q.shape[-2]
+        if k is None and v is None:  # self-attention: one projection over the concatenated q/k/v weight
+            lead = q.shape[:-2]
+            w, b = self._pack("qkv")
+            qkv = ops.linear(q.reshape(-1, q.shape[-1]), w, b).view(-1, Lq, 3 * inner)
+            qh, kh, vh = qkv[..., :inner], qkv[..., inner : 2 * inner], qkv[..., 2 * inner :]
+        else:
+            k = q if k is None else k
+            Lk = k.shape[-2]
+            lead = torch.broadcast_shapes(q.shape[:-2], k.shape[:-2])  # e.g. a (1, 1, d) probe over (N, L, d)
+            qh = self.q_proj(q)
+            if v is None or v is k:
+                w, b = self._pack("kv")
+                kv = ops.linear(k.reshape(-1, k.shape[-1]), w, b).view(*k.shape[:-1], 2 * inner)
+                kh, vh = kv[..., :inner], kv[..., inner:]
+            else:
+                kh, vh = self.k_proj(k), self.v_proj(v)
+            # broadcast AFTER projecting: an expanded operand is a stride-0 view, never a copy of the projection
+            qh = qh.expand(*lead, Lq, inner).reshape(-1, Lq, inner)
+            kh = kh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
+            vh = vh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
+        o = ops.attention(qh, kh, vh, H, causal)
+        res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
+        y = ops.linear(o.view(-1, inner), self.out_proj.weight, _f32(self.out_proj, "b", self.out_proj.bias), resid=res2)
+        return y.view(*lead, Lq, y.shape[-1])
+
+
+class MLP(nn.Module):
+    """linear1 -> act -> linear2 -> dropout (child names as in the reference's nn.Sequential, transformer.py:56-67)."""
+
+    def __init__(self, in_dim: int, hidden_dim: float, dropout: float = 0.0, act: str = "gelu") -> None:
+        super().__init__()
+        self.linear1 = Linear(in_dim, hidden_dim)
+        self.act = _ACTS[act]()
+        self.linear2 = Linear(hidden_dim, in_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.act_name = act
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.run(x)
+
+    def run(self, x: Tensor, residual: Tensor | None = None) -> Tensor:
+        _require_bf16(x, self.linear1.weight, "MLP")
+        if self.training and self.dropout.p > 0.0:
+            raise NotImplementedError("MLP: inference only (dropout is not implemented)")
+        x2 = x.reshape(-1, x.shape[-1])
+        h = ops.linear(x2, self.linear1.weight, _f32(self.linear1, "b", self.linear1.bias), act=self.act_name)
+        res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
+        y = ops.linear(h, self.linear2.weight, _f32(self.linear2, "b", self.linear2.bias), resid=res2)
+        return y.view(*x.shape)
+
+
+def _fused_attend(mha: MHA, x: Tensor, kv: Tensor | None, causal: bool, residual: Tensor) -> Tensor:
+    if type(mha).forward is MHA.forward:  # plain MHA: residual add rides in the out_proj epilogue
+        return mha.attend(x, kv, None, None, causal, residual=residual)
+    return residual + (mha(x, kv, causal=causal) if kv is not None else mha(x, causal=causal))  # subclassed MHA
+
+
+def _fused_mlp(mlp: MLP, x: Tensor, residual: Tensor) -> Tensor:
+    if type(mlp).forward is MLP.forward:
+        return mlp.run(x, residual=residual)
+    return residual + mlp(x)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(
+        self,
+        d_model: int,
+        n_heads: int | None = None,
+        head_dim: int | None = None,
+        cross_attn: bool = False,
+        bias: bool = True,
+        mlp_ratio: float = 4.0,
+        dropout: float = 0.0,
+        act: str = "gelu",
+        pre_norm: bool = True,
+        norm_eps: float = 1e-5,
+    ) -> None:
+        super().__init__()
+        self.pre_norm = pre_norm
+        self.sa_norm = LayerNorm(d_model, norm_eps)
+        self.sa = MHA(d_model, n_heads, head_dim, bias, dropout)
+        self.ca_norm = LayerNorm(d_model, norm_eps) if cross_attn else None
+        self.ca = MHA(d_model, n_heads, head_dim, bias, dropout) if cross_attn else None
+        self.mlp_norm = LayerNorm(d_model, norm_eps)
+        self.mlp = MLP(d_model, int(d_model * mlp_ratio), dropout, act)
+
+    _self_causal = True
+
+    def forward(self, x: Tensor, memory: Tensor | None = None) -> Tensor:
+        c = self._self_causal
+        if self.pre_norm:
+            x = _fused_attend(self.sa, self.sa_norm(x), None, c, x)
+            if self.ca is not None:
+                x = _fused_attend(self.ca, self.ca_norm(x), memory, False, x)
+            x = _fused_mlp(self.mlp, self.mlp_norm(x), x)
+        else:
+            x = self.sa_norm(_fused_attend(self.sa, x, None, c, x))
+            if self.ca is not None:
+                x = self.ca_norm(_fused_attend(self.ca, x, memory, False, x))
+            x = self.mlp_norm(_fused_mlp(self.mlp, x, x))
+        return x
+
+
+class EncoderLayer(DecoderLayer):
+    _self_causal = False
+
+    def __init__(
+        self,
+        d_model: int,
+        n_heads: int | None = None,
+        head_dim: int | None = None,
+        bias: bool = True,
+        mlp_ratio: float = 4.0,
+        dropout: float = 0.0,
+        act: str = "gelu",
+        pre_norm: bool = True,
+        norm_eps: float = 1e-5,
+    ) -> None:
+        super().__init__(d_model, n_heads, head_dim, False, bias, mlp_ratio, dropout, act, pre_norm, norm_eps)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return DecoderLayer.forward(self, x, None)
+
+
+class Encoder(nn.Sequential):
+    def __init__(
+        self,
+        n_layers: int,
+        d_model: int,
+        n_heads: int | None = None,
+        head_dim: int | None = None,
+        bias: bool = True,
+        mlp_ratio: float = 4.0,
+        dropout: float = 0.0,
+        act: str = "gelu",
+        pre_norm: bool = True,
+        norm_eps: float = 1e-5,
+    ) -> None:
+        super().__init__(*[
+            EncoderLayer(d_model, n_heads, head_dim, bias, mlp_ratio, dropout, act, pre_norm, norm_eps)
+            for _ in range(n_layers)
+        ])
+
+
+class Decoder(nn.ModuleList):
+    def __init__(
+        self,
+        n_layers: int,
+        d_model: int,
+        n_heads: int | None = None,
+        head_dim: int | None = None,
+        cross_attn: bool = False,
+        bias: bool = True,
+        mlp_ratio: float = 4.0,
+        dropout: float = 0.0,
+        act: str = "gelu",
+        pre_norm: bool = True,
+        norm_eps: float = 1e-5,
+    ) -> None:
+        super().__init__([
+            DecoderLayer(d_model, n_heads, head_dim, cross_attn, bias, mlp_ratio, dropout, act, pre_norm, norm_eps)
+            for _ in range(n_layers)
+        ])
+
+    def forward(self, x: Tensor, memory: Tensor | None = None) -> Tensor:
+        for layer in self:
+            x = layer(x, memory)
+        return x

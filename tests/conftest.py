@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "pytorch-models_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    import numpy as np
+    import torch
+
+    def load(name):
+        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+        out = {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+        out["meta"] = json.loads(bytes(z["meta"]).decode())
+        return out
+
+    return load

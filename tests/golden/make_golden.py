@@ -1,0 +1,267 @@
+"""Generate tests/golden/*.npz by IMPORTING THE REFERENCE on CPU (build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference; never runs on the GPU box
+
+Weights and inputs come from ``synthweights`` (numpy PCG64 keyed by parameter name), so the
+fixtures hold only expected OUTPUTS (or slices / digests of large ones) plus the seeds and
+shapes needed to regenerate the inputs.  Nothing of the reference's source travels: a fixture is
+data.  The tests in tests/test_oracle_golden.py pin the oracle (oracle/) to these vectors.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")  # the reference's ``pytorch_models`` wins
+sys.path.insert(1, os.path.join(ROOT, "pytorch-models_amd"))  # only for ``synthweights``
+
+import pytorch_models  # noqa: E402
+
+assert pytorch_models.__file__.startswith("/root/reference"), pytorch_models.__file__
+from pytorch_models.audio.spectrogram import MelSpectrogram, Spectrogram, get_mel_filters  # noqa: E402
+from pytorch_models.audio2text import Whisper, WhisperDecoder, WhisperEncoder, WhisperPreprocessor  # noqa: E402
+from pytorch_models.image import ViT  # noqa: E402
+from pytorch_models.transformer import MHA, Decoder, DecoderLayer, Encoder, EncoderLayer  # noqa: E402
+from synthweights import fill_module, synth_input, synth_tokens  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def save(name, meta=None, **arrays):
+    out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    out["meta"] = np.frombuffer(json.dumps(meta or {}).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def digest(t: torch.Tensor) -> np.ndarray:
+    """Order-sensitive digest of a large tensor: [sum, sum|x|, sum x*w] in fp64, w = 1 + (i mod 251)/251."""
+    f = t.double().flatten()
+    w = 1.0 + (torch.arange(f.numel(), dtype=torch.float64) % 251) / 251.0
+    return np.array([f.sum().item(), f.abs().sum().item(), (f * w).sum().item()])
+
+
+# ---------------------------------------------------------------- 1/2: transformer blocks
+def g_blocks():
+    d = 64
+    out = {}
+    x = synth_input("blk_x", (2, 10, d), 1)
+    mem = synth_input("blk_mem", (2, 7, d), 1)
+    for pre in (True, False):
+        for eps in (1e-5, 1e-6):
+            m = EncoderLayer(d, pre_norm=pre, norm_eps=eps).eval()
+            fill_module(m, 11)
+            out[f"enc_pre{int(pre)}_eps{eps}"] = m(x)
+            m = DecoderLayer(d, cross_attn=True, pre_norm=pre, norm_eps=eps).eval()
+            fill_module(m, 12)
+            out[f"dec_pre{int(pre)}_eps{eps}"] = m(x, mem)
+    m = DecoderLayer(d, cross_attn=False).eval()  # decoder-only (GPT-style) path of transformer.py:99
+    fill_module(m, 13)
+    out["dec_nocross"] = m(x)
+    for act in ("gelu", "approximate_gelu", "relu", "silu"):
+        m = EncoderLayer(d, act=act).eval()
+        fill_module(m, 14)
+        out[f"enc_act_{act}"] = m(x)
+    m = Encoder(3, 128, n_heads=2).eval()
+    fill_module(m, 15)
+    out["encoder3"] = m(synth_input("blk_x128", (2, 9, 128), 1))
+    m = Decoder(2, 128, cross_attn=True).eval()
+    fill_module(m, 16)
+    out["decoder2"] = m(synth_input("blk_x128", (2, 9, 128), 1), synth_input("blk_mem128", (2, 5, 128), 1))
+    save("blocks", dict(d=d), **out)
+
+
+def g_mha():
+    d = 64
+    q = synth_input("mha_q", (2, 6, d), 2)
+    k = synth_input("mha_k", (2, 9, d), 2)
+    v = synth_input("mha_v", (2, 9, d), 2)
+    bias = synth_input("mha_bias", (2, 1, 6, 9), 2)
+    out = {}
+    m = MHA(d).eval()  # default: head_dim 64 -> 1 head
+    fill_module(m, 21)
+    out["default_q"] = m(q)
+    m = MHA(d, n_heads=4).eval()
+    fill_module(m, 22)
+    out["h4_q"] = m(q)
+    out["h4_qk"] = m(q, k)
+    out["h4_qkv"] = m(q, k, v)
+    out["h4_bias"] = m(q, k, v, attn_bias=bias)
+    out["h4_causal"] = m(q, causal=True)
+    out["h4_causal_rect"] = m(q, k, causal=True)  # top-left aligned, L_q != S_k
+    out["h4_unbatched"] = m(q[0])  # (L, d) leading-dim-free input (tests/text/test_t5.py:27-29)
+    m = MHA(d, n_heads=2, head_dim=16).eval()  # n_heads * head_dim < d_model (transformer.py:18)
+    fill_module(m, 23)
+    out["h2hd16_q"] = m(q)
+    m = MHA(d, head_dim=32, bias=False).eval()
+    fill_module(m, 24)
+    out["hd32_nobias"] = m(q, k)
+    save("mha", dict(d=d), **out)
+
+
+def g_sdpa_alignment():
+    # F3: L_q = 1, S_k = 5, is_causal=True -> only key 0 visible
+    q = synth_input("f3_q", (1, 1, 1, 8), 3)
+    k = synth_input("f3_k", (1, 1, 5, 8), 3)
+    v = synth_input("f3_v", (1, 1, 5, 8), 3)
+    out = torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True)
+    save("sdpa_alignment", {}, out=out, v0=v[:, :, 0])
+
+
+# ---------------------------------------------------------------- ViT
+def g_vit():
+    out = {}
+    m = ViT.from_google("Ti/16").eval()
+    fill_module(m, 31)
+    x = synth_input("vit_ti", (1, 3, 224, 224), 31)
+    out["ti16_b1"] = m(x)
+    # intermediate: tokens after patch-embed + pe + cls (vit.py:78-81)
+    t = m.patch_embed(x).flatten(-2).transpose(-1, -2) + m.pe
+    t = torch.cat([m.cls_token, t], dim=-2)
+    out["ti16_tokens_slice"] = t[0, :5, :16]
+    out["ti16_tokens_digest"] = digest(t)
+    # resize_pe(256) then forward at 256 (tests/image/test_vit.py:21-26)
+    m.resize_pe(256)
+    out["ti16_pe256"] = m.pe.detach().clone()
+    out["ti16_b1_256"] = m(synth_input("vit_ti256", (1, 3, 256, 256), 31))
+
+    m = ViT.from_google("B/16").eval()
+    fill_module(m, 32)
+    xb = synth_input("vit_b", (4, 3, 224, 224), 32)
+    out["b16_first4"] = torch.cat([m(xb[i : i + 1]) for i in range(4)])  # F1: per-sample loop
+
+    m = ViT.from_google("B/16_siglip").eval()
+    fill_module(m, 33)
+    out["b16_siglip_b2"] = m(synth_input("vit_bs", (2, 3, 224, 224), 33))
+
+    m = ViT.from_google("L/16_siglip", img_size=384).eval()
+    fill_module(m, 34)
+    out["l16_siglip384_b2"] = m(synth_input("vit_ls", (2, 3, 384, 384), 34))
+
+    m = ViT.from_facebook("S/14_dinov2").eval()  # img 518, patch 14 -> L = 1370
+    fill_module(m, 35)
+    out["s14_dinov2_b1"] = m(synth_input("vit_dv2", (1, 3, 518, 518), 35))
+
+    m = ViT(2, 128, 2, 16, img_size=64, pool_type="gap").eval()
+    fill_module(m, 36)
+    out["tiny_gap_b1"] = m(synth_input("vit_gap", (1, 3, 64, 64), 36))
+    m = ViT(2, 128, 2, 16, img_size=64, cls_token=False, pool_type="gap").eval()
+    fill_module(m, 37)
+    out["tiny_gap_nocls_b3"] = m(synth_input("vit_gap3", (3, 3, 64, 64), 37))
+    save("vit", {}, **out)
+
+
+# ---------------------------------------------------------------- spectrogram / log-mel
+def g_audio():
+    out = {}
+    out["filters80"] = get_mel_filters(80, 400, 16000)
+    out["filters128"] = get_mel_filters(128, 400, 16000)
+    x1 = synth_input("wave_1s", (16000,), 41)
+    out["spec_1s"] = Spectrogram(400, 160)(x1)  # (201, 101)
+    out["mel_1s"] = MelSpectrogram(400, 160, 80, 16000)(x1)  # (80, 101)
+    out["logmel_1s"] = WhisperPreprocessor()(x1)  # (80, 100)
+    out["logmel128_1s"] = WhisperPreprocessor("large-v3")(x1)
+    x30 = synth_input("wave_30s", (2, 480000), 42, scale=0.1)
+    lm = WhisperPreprocessor("base")(x30)  # (2, 80, 3000)
+    out["logmel_30s_digest"] = digest(lm)
+    out["logmel_30s_slice"] = lm[:, ::8, ::100]
+    out["logmel_30s_head"] = lm[0, :, :8]
+    out["logmel_30s_tail"] = lm[1, :, -8:]
+    # tests/audio2text/test_whisper.py:57-65: batched == per-sample (F4) with a DC offset on sample 0
+    xb = synth_input("wave_batch", (4, 16000), 43)
+    xb[0] += 0.5
+    out["logmel_batch"] = WhisperPreprocessor()(xb)
+    # a silent clip: clamp(0).log10() = -inf everywhere, max - 8 = -inf -> stays -inf (edge case of whisper.py:145-146)
+    xs = synth_input("wave_half_silent", (16000,), 44)
+    xs[8000:] = 0
+    out["logmel_half_silent"] = WhisperPreprocessor()(xs)
+    save("audio", {}, **out)
+
+
+# ---------------------------------------------------------------- Whisper
+def g_whisper():
+    out = {}
+    # smoke shapes of tests/audio2text/test_whisper.py:10-17
+    vocab, L, d = 100, 2, 64
+    enc = WhisperEncoder(L, d).eval()
+    fill_module(enc, 51)
+    mel = synth_input("w_mel16", (2, 80, 16), 51)
+    out["smoke_encoder"] = enc(mel)
+    dec = WhisperDecoder(vocab, L, d).eval()
+    fill_module(dec, 52)
+    toks = synth_tokens("w_tok32", (2, 32), vocab, 52)
+    out["smoke_decoder"] = dec(toks, synth_input("w_mem16", (2, 16, d), 52))
+    w = Whisper(vocab, L, d).eval()
+    fill_module(w, 53)
+    out["smoke_whisper"] = w(mel, toks)
+
+    # reference-test shape (tests/audio2text/test_whisper.py:39-42) on "tiny" geometry
+    w = Whisper.from_openai("tiny").eval()
+    fill_module(w, 54)
+    mel = synth_input("w_mel3000", (1, 80, 3000), 54)
+    toks = synth_tokens("w_tok200", (1, 32), 200, 54)
+    memory = w.encoder(mel)
+    logits = w.decoder(toks, memory)
+    out["tiny_memory_digest"] = digest(memory)
+    out["tiny_memory_slice"] = memory[0, ::100, ::32]
+    out["tiny_logits_digest"] = digest(logits)
+    out["tiny_logits_slice"] = logits[0, :, :128]
+    out["tiny_logits_argmax"] = logits.argmax(-1)
+    out["tiny_logits_max"] = logits.max(-1).values
+
+    # greedy ids by full-prefix recompute: B=2, prompt 4, 32 new tokens, with top1-top2 margins
+    for tag, seed in (("tiny", 55), ("base", 56)):
+        w = Whisper.from_openai(tag).eval()
+        fill_module(w, seed)
+        wave = synth_input(f"w_wave_{tag}", (2, 480000), seed, scale=0.1)
+        mel = WhisperPreprocessor(tag)(wave)
+        memory = w.encoder(mel)
+        toks = synth_tokens(f"w_prompt_{tag}", (2, 4), 51865, seed)
+        margins = []
+        for _ in range(32):
+            last = w.decoder(toks, memory)[:, -1]
+            top2 = last.topk(2, -1)
+            margins.append(top2.values[:, 0] - top2.values[:, 1])
+            toks = torch.cat([toks, top2.indices[:, :1]], 1)
+        out[f"greedy_{tag}_tokens"] = toks
+        out[f"greedy_{tag}_margins"] = torch.stack(margins, 1)
+        out[f"greedy_{tag}_memory_digest"] = digest(memory)
+        out[f"greedy_{tag}_memory_slice"] = memory[:, ::100, ::32]
+        print(tag, "layers", len(w.encoder.layers), "min margin", float(torch.stack(margins, 1).min()))
+    save("whisper", {}, **out)
+
+
+def g_geometry():
+    """Constructor contract: parameter names / shapes / counts of every hot-path constructor."""
+    rec = {}
+    for tag in ("Ti/16", "B/16", "B/16_siglip"):
+        m = ViT.from_google(tag)
+        rec["google:" + tag] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    m = ViT.from_google("L/16_siglip", img_size=384)
+    rec["google:L/16_siglip@384"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    for tag in ("S/16_deit3", "S/16_dino", "S/14_dinov2"):
+        m = ViT.from_facebook(tag)
+        rec["facebook:" + tag] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    for tag in ("tiny", "tiny.en", "base", "large-v3"):
+        with torch.device("meta"):
+            m = Whisper.from_openai(tag)
+        rec["openai:" + tag] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    p = WhisperPreprocessor()
+    rec["preprocessor"] = {k: list(v.shape) for k, v in p.state_dict().items()}
+    with open(os.path.join(HERE, "geometry.json"), "w") as f:
+        json.dump(rec, f, indent=0, sort_keys=True)
+    print("geometry.json", os.path.getsize(os.path.join(HERE, "geometry.json")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry"]
+    table = dict(blocks=g_blocks, mha=g_mha, sdpa=g_sdpa_alignment, vit=g_vit, audio=g_audio, whisper=g_whisper,
+                 geometry=g_geometry)
+    for w in which:
+        table[w]()
