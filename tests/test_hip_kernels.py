@@ -1,0 +1,211 @@
+"""GPU parity of each C-ABI kernel against the oracle's primitive on the same seeded inputs.
+
+bf16 tolerance (stated): operands are bf16-rounded BEFORE both paths see them, the oracle computes in
+fp32, the kernel accumulates in fp32 and rounds its output to bf16 once (2^-9 relative).  We therefore
+require |got - want| <= 1e-2 * |want| + 1e-2 * rms(want) for bf16 outputs, and 1e-4-level agreement for
+fp32 outputs (accumulation-order differences only).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_transformer as RT
+from oracle import ref_vit as RV
+from synthweights import synth_input
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def close_bf16(got, want, rel=1e-2):
+    got, want = got.float().cpu(), want.float()
+    rms = want.square().mean().sqrt().item()
+    torch.testing.assert_close(got, want, rtol=rel, atol=rel * max(rms, 1e-6))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from pytorch_models._hip import ops as o
+
+    return o
+
+
+# ---------------------------------------------------------------- linear
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 768, 768), (1, 64, 64), (333, 2304, 768), (50, 192, 3072), (257, 132, 128)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_linear_shapes(ops, M, N, K, act):
+    x = bf(synth_input("lin_x", (M, K), 1))
+    w = bf(synth_input("lin_w", (N, K), 2, scale=1 / math.sqrt(K)))
+    b = synth_input("lin_b", (N,), 3, scale=0.1)
+    want = x.float() @ w.float().T + b
+    want = want if act == "none" else RT.activation(want, act)
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=act)
+    assert got.dtype == torch.bfloat16 and got.shape == (M, N)
+    close_bf16(got, want)
+
+
+@pytest.mark.parametrize("act", ["approximate_gelu", "relu", "silu"])
+def test_linear_activations(ops, act):
+    x = bf(synth_input("lin_x", (70, 128), 1))
+    w = bf(synth_input("lin_w", (96, 128), 2, scale=0.1))
+    want = RT.activation(x.float() @ w.float().T, act)
+    close_bf16(ops.linear(x.cuda(), w.cuda(), None, act=act), want)
+
+
+@pytest.mark.parametrize("rdt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_linear_residual_and_dtypes(ops, rdt, odt):
+    M, N, K = 200, 256, 192
+    x = bf(synth_input("lin_x", (M, K), 4))
+    w = bf(synth_input("lin_w", (N, K), 5, scale=0.07))
+    b = synth_input("lin_b", (N,), 6, scale=0.1)
+    r = synth_input("lin_r", (M, N), 7).to(rdt)
+    want = x.float() @ w.float().T + b + r.float()
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), resid=r.cuda(), out_dtype=odt)
+    assert got.dtype == odt
+    if odt == torch.float32:
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-4)
+    else:
+        close_bf16(got, want)
+
+
+def test_linear_strided_views_and_inplace_residual(ops):
+    """x as a column slice of a wider buffer (ldx > K); residual aliased with the output."""
+    M, N, K = 130, 128, 64
+    wide = bf(synth_input("lin_wide", (M, 3 * K), 8)).cuda()
+    x = wide[:, K : 2 * K]
+    w = bf(synth_input("lin_w", (N, K), 9, scale=0.1)).cuda()
+    acc = bf(synth_input("lin_acc", (M, N), 10)).cuda()
+    want = x.float().cpu() @ w.float().cpu().T + acc.float().cpu()
+    ops.linear(x, w, None, resid=acc, out=acc)
+    close_bf16(acc, want)
+
+
+def test_linear_rejects_unsupported(ops):
+    x = torch.zeros(4, 72, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(8, 72, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="pm_mi355x error 2"):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        ops.linear(x.cpu(), w.cpu())
+
+
+def test_linear_linearity_at_full_size(ops):
+    """Size-independent property at the BASELINE C2 shape (M = 256*197): f(x + x) == 2 f(x) bit-exactly (no bias)."""
+    M, N, K = 50432, 768, 768
+    x1 = bf(synth_input("big_x1", (M, K), 11)).cuda()
+    w = bf(synth_input("big_w", (N, K), 13, scale=1 / math.sqrt(K))).cuda()
+    # x2 = x1, so the sum 2 * x1 is exactly representable in bf16
+    y1 = ops.linear(x1, w, None, out_dtype=torch.float32)
+    y2 = ops.linear((x1.float() * 2).to(torch.bfloat16), w, None, out_dtype=torch.float32)
+    torch.testing.assert_close(y2, 2 * y1, rtol=0, atol=0)  # power-of-two scaling is bit-exact in fp32
+    # and a spot check of 64 random rows against the oracle
+    idx = torch.randint(0, M, (64,), generator=torch.Generator().manual_seed(0))
+    want = x1[idx.cuda()].float().cpu() @ w.float().cpu().T
+    torch.testing.assert_close(y1[idx.cuda()].cpu(), want, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- layernorm
+@pytest.mark.parametrize("M,d", [(5, 64), (197, 192), (1000, 768), (33, 1280), (7, 4096), (64, 8)])
+@pytest.mark.parametrize("eps", [1e-5, 1e-6])
+def test_layernorm(ops, M, d, eps):
+    x = bf(synth_input("ln_x", (M, d), 20)) * 3 + 1
+    g = synth_input("ln_g", (d,), 21, scale=0.1) + 1
+    b = synth_input("ln_b", (d,), 22, scale=0.1)
+    want = RT.layernorm({"weight": g, "bias": b}, "", x.float(), eps)
+    close_bf16(ops.layernorm(x.cuda(), g.cuda(), b.cuda(), eps), want)
+    got32 = ops.layernorm(x.float().cuda(), g.cuda(), b.cuda(), eps, out_dtype=torch.float32)
+    torch.testing.assert_close(got32.cpu(), want, rtol=2e-5, atol=2e-5)
+
+
+def test_layernorm_strided_rows(ops):
+    """Row stride > d: normalising only the cls row of (N, L, d) (ViT pooled-row shortcut)."""
+    x = bf(synth_input("ln_x3", (6, 5, 64), 23)).cuda()
+    g = torch.ones(64, device="cuda")
+    b = torch.zeros(64, device="cuda")
+    want = RT.layernorm({"weight": g.cpu(), "bias": b.cpu()}, "", x[:, 0].float().cpu(), 1e-6)
+    close_bf16(ops.layernorm(x[:, 0], g, b, 1e-6), want)
+
+
+# ---------------------------------------------------------------- attention
+def ref_attn(q, k, v, H, causal):
+    qh, kh, vh = (RT.split_heads(t.float(), H) for t in (q, k, v))
+    return RT.merge_heads(RT.sdpa(qh, kh, vh, None, causal))
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 3, 197, 197), (1, 1, 1, 1), (2, 2, 64, 64), (1, 2, 130, 577), (1, 8, 1500, 1500),
+                                       (3, 1, 1, 300), (2, 4, 33, 5), (1, 1, 128, 128), (1, 2, 129, 63)])
+def test_attention_noncausal(ops, B, H, Lq, Lk):
+    q = bf(synth_input("at_q", (B, Lq, H * 64), 30))
+    k = bf(synth_input("at_k", (B, Lk, H * 64), 31))
+    v = bf(synth_input("at_v", (B, Lk, H * 64), 32))
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    close_bf16(got, ref_attn(q, k, v, H, False), rel=1.5e-2)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 2, 4, 4), (1, 3, 200, 200), (2, 1, 448, 448), (1, 2, 6, 9), (1, 1, 130, 40), (1, 1, 1, 5)])
+def test_attention_causal_top_left(ops, B, H, Lq, Lk):
+    """causal is top-left aligned, including rectangular Lq != Lk."""
+    q = bf(synth_input("at_q", (B, Lq, H * 64), 33))
+    k = bf(synth_input("at_k", (B, Lk, H * 64), 34))
+    v = bf(synth_input("at_v", (B, Lk, H * 64), 35))
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, causal=True)
+    close_bf16(got, ref_attn(q, k, v, H, True), rel=1.5e-2)
+
+
+def test_attention_packed_qkv_and_broadcast_query(ops):
+    B, L, H = 2, 77, 2
+    qkv = bf(synth_input("at_qkv", (B, L, 3 * H * 64), 36)).cuda()
+    q, k, v = qkv[..., : H * 64], qkv[..., H * 64 : 2 * H * 64], qkv[..., 2 * H * 64 :]
+    close_bf16(ops.attention(q, k, v, H), ref_attn(q.cpu(), k.cpu(), v.cpu(), H, False), rel=1.5e-2)
+    probe = bf(synth_input("at_probe", (1, 1, H * 64), 37)).cuda().expand(B, 1, H * 64)  # stride-0 batch (MAP head)
+    close_bf16(ops.attention(probe, k, v, H), ref_attn(probe.cpu(), k.cpu(), v.cpu(), H, False), rel=1.5e-2)
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """Force the running max to jump at a late key tile (a spike), so the rescale path is exercised."""
+    B, H, L = 1, 1, 300
+    q = bf(synth_input("at_q", (B, L, 64), 38))
+    k = bf(synth_input("at_k", (B, L, 64), 39))
+    v = bf(synth_input("at_v", (B, L, 64), 40))
+    k[0, 257] = q[0, 10] * 4  # key 257 (tile 4) dominates query 10
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    close_bf16(got, ref_attn(q, k, v, H, False), rel=1.5e-2)
+
+
+def test_attention_rows_sum_property_at_full_size(ops):
+    """Size-independent property at the C2 shape: with v == 1 every output element is exactly 1
+    (softmax rows sum to one), for all 256*12 heads and 197 tokens."""
+    B, H, L = 256, 12, 197
+    q = bf(synth_input("at_qf", (B, L, H * 64), 41)).cuda()
+    k = bf(synth_input("at_kf", (B, L, H * 64), 42)).cuda()
+    v = torch.ones(B, L, H * 64, dtype=torch.bfloat16, device="cuda")
+    out = ops.attention(q, k, v, H).float()
+    assert (out - 1).abs().max().item() <= 2 ** -7  # bf16(p) rounding in P.V, renormalised by the fp32 row sum
+
+
+# ---------------------------------------------------------------- ViT token assembly
+@pytest.mark.parametrize("N,img,d,cls", [(1, 224, 192, True), (3, 64, 128, False), (2, 384, 1024, False), (5, 32, 64, True)])
+def test_vit_tokens(ops, N, img, d, cls):
+    P = 16
+    L = (img // P) ** 2
+    imgs = synth_input("vt_img", (N, 3, img, img), 50)
+    sd = {
+        "patch_embed.weight": bf(synth_input("vt_w", (d, 3, P, P), 51, scale=0.04)).float(),
+        "patch_embed.bias": synth_input("vt_b", (d,), 52, scale=0.1),
+        "pe": synth_input("vt_pe", (1, L, d), 53, scale=0.1),
+    }
+    if cls:
+        sd["cls_token"] = synth_input("vt_cls", (1, 1, d), 54, scale=0.1)
+    # the kernel rounds pixels to bf16 before the MFMA: mirror that rounding point in the oracle
+    want = RV.tokens(sd, bf(imgs).float())
+    got = ops.vit_tokens(imgs.cuda(), bf(sd["patch_embed.weight"]).view(d, -1).cuda(), sd["patch_embed.bias"].cuda(),
+                         sd["pe"].view(L, d).cuda(), sd["cls_token"].view(-1).cuda() if cls else None, P)
+    assert got.shape == (N, L + int(cls), d)
+    close_bf16(got, want)

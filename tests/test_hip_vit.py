@@ -1,0 +1,109 @@
+"""GPU parity of ViT.forward (HIP path, bf16) against the oracle and the reference's golden vectors.
+
+Stated bf16 tolerance: the oracle runs in fp32 on the SAME bf16-rounded weights; the HIP path keeps
+activations (residual stream included) in bf16 with fp32 accumulation, so after 12-24 pre-norm layers
+the pooled, LayerNorm-ed output agrees to rel-L2 <= 2e-2 and max-abs <= 8e-2 (outputs are O(1)).
+Against the reference's fp32 goldens (fp32 weights) the same bounds hold because weight rounding adds
+an error of the same order.
+"""
+import pytest
+import torch
+
+from oracle import ref_vit as RV
+from synthweights import bf16_round_, fill_module, synth_input
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+REL_L2, MAX_ABS = 2e-2, 8e-2
+
+
+def check(got, want):
+    got, want = got.float().cpu(), want.float()
+    rel = ((got - want).norm() / want.norm()).item()
+    mx = (got - want).abs().max().item()
+    assert rel <= REL_L2 and mx <= MAX_ABS, (rel, mx)
+    return rel
+
+
+def build(tag_fn, seed, **kw):
+    from pytorch_models.image import ViT
+
+    m = tag_fn(ViT, **kw).eval()
+    fill_module(m, seed)
+    ref_sd32 = {k: v.clone() for k, v in m.state_dict().items()}
+    bf16_round_(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    return m.to(torch.bfloat16).cuda(), sd, ref_sd32
+
+
+def test_vit_ti16_b1_config1(golden):
+    """BASELINE config[0]: ViT-Ti/16 augreg, batch 1, 224x224 - vs oracle and vs the reference golden."""
+    m, sd, _ = build(lambda V: V.from_google("Ti/16"), 31)
+    x = synth_input("vit_ti", (1, 3, 224, 224), 31)
+    got = m(x.cuda())
+    assert got.shape == (1, 192) and got.dtype == torch.bfloat16
+    check(got, RV.forward(sd, RV.geometry_from_google("Ti/16"), x))
+    check(got, golden("vit")["ti16_b1"])
+    # token assembly alone, against the golden slice of the reference's conv + pe + cls
+    t = m.tokens(x.cuda())
+    torch.testing.assert_close(t[0, :5, :16].float().cpu(), golden("vit")["ti16_tokens_slice"], rtol=2e-2, atol=2e-2)
+
+
+def test_vit_cls_batch_gt1_is_stack_of_batch1(golden):
+    """F1: batch 4 with a cls token equals the reference's per-sample loop (and the batch-1 HIP results)."""
+    m, sd, _ = build(lambda V: V.from_google("B/16"), 32)
+    xb = synth_input("vit_b", (4, 3, 224, 224), 32)
+    got = m(xb.cuda())
+    check(got, golden("vit")["b16_first4"])
+    check(got, RV.forward(sd, RV.geometry_from_google("B/16"), xb))
+    one = torch.cat([m(xb[i : i + 1].cuda()) for i in range(4)])
+    torch.testing.assert_close(got, one, rtol=0, atol=0)  # batch-invariant: same kernels, same tiles per row
+
+
+def test_vit_siglip_map_head(golden):
+    m, sd, _ = build(lambda V: V.from_google("B/16_siglip"), 33)
+    x = synth_input("vit_bs", (2, 3, 224, 224), 33)
+    got = m(x.cuda())
+    check(got, golden("vit")["b16_siglip_b2"])
+    check(got, RV.forward(sd, RV.geometry_from_google("B/16_siglip"), x))
+
+
+def test_vit_l16_siglip384_config5_geometry(golden):
+    m, sd, _ = build(lambda V: V.from_google("L/16_siglip", img_size=384), 34)
+    x = synth_input("vit_ls", (2, 3, 384, 384), 34)
+    got = m(x.cuda())
+    assert got.shape == (2, 1024)
+    check(got, golden("vit")["l16_siglip384_b2"])
+
+
+def test_vit_gap_pooler_and_resize_pe(golden):
+    from pytorch_models.image import ViT
+
+    m = ViT(2, 128, 2, 16, img_size=64, pool_type="gap").eval()
+    fill_module(m, 36)
+    bf16_round_(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = synth_input("vit_gap", (1, 3, 64, 64), 36)
+    check(m.to(torch.bfloat16).cuda()(x.cuda()), RV.forward(sd, RV.ViTGeometry(2, 128, 2, 16, 64, True, "gap"), x))
+    m2, sd2, _ = build(lambda V: V.from_google("Ti/16"), 31)
+    m2.resize_pe(256)
+    x = synth_input("vit_ti256", (1, 3, 256, 256), 31)
+    check(m2(x.cuda()), golden("vit")["ti16_b1_256"])
+    with pytest.raises(ValueError, match="resize_pe"):
+        m2(synth_input("vit_ti", (1, 3, 224, 224), 31).cuda())  # pe no longer matches a 224 image
+
+
+def test_vit_b16_full_batch_256_properties():
+    """BASELINE config[1] at full size: ViT-B/16, batch 256.  The oracle is too slow for 256 images, so:
+    (a) rows 0..3 equal the batch-4 run bit-exactly (batch invariance), which the test above ties to the oracle;
+    (b) permuting the batch permutes the output rows bit-exactly; (c) outputs are finite."""
+    m, _, _ = build(lambda V: V.from_google("B/16"), 32)
+    xb4 = synth_input("vit_b", (4, 3, 224, 224), 32).cuda()
+    big = synth_input("vit_b256", (256, 3, 224, 224), 77).cuda()
+    big[:4] = xb4
+    out = m(big)
+    assert out.shape == (256, 768) and torch.isfinite(out.float()).all()
+    torch.testing.assert_close(out[:4], m(xb4), rtol=0, atol=0)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(1)).cuda()
+    torch.testing.assert_close(m(big[perm]), out[perm], rtol=0, atol=0)
