@@ -13,6 +13,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing (bench.py's roofline leg): when LAUNCH_LOG is a dict, every wrapped launch is
+# bracketed by two HIP events recorded on the stream the kernel is launched on.
+LAUNCH_LOG: dict | None = None
+
+
+def _launch(name: str, work: float, fn):
+    if LAUNCH_LOG is None:
+        return fn()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    rc = fn()
+    e1.record(st)
+    LAUNCH_LOG.setdefault(name, []).append((e0, e1, work))
+    return rc
+
+
 def _dt(t: Tensor) -> int:
     if t.dtype == torch.bfloat16:
         return PM_BF16
@@ -51,10 +68,10 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none
     _need(out.shape == (M, N) and out.stride(1) == 1, "linear: bad out")
     if resid is not None:
         _need(resid.shape == (M, N) and resid.stride(1) == 1, "linear: resid must be (M, N), row-major")
-    rc = lib().pm_linear_bf16(
+    rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16(
         x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
         resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
-        _dt(resid) if resid is not None else 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream())
+        _dt(resid) if resid is not None else 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream()))
     check(rc, f"pm_linear_bf16(M={M}, N={N}, K={K})")
     return out
 
@@ -67,8 +84,9 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: tor
     _need(gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == d and beta.numel() == d,
           "layernorm: gamma / beta must be f32 (d)")
     out = torch.empty((M, d), dtype=out_dtype or x.dtype, device=x.device)
-    rc = lib().pm_layernorm(x.data_ptr(), x.stride(0), _dt(x), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                            out.data_ptr(), out.stride(0), _dt(out), M, d, _stream())
+    rc = _launch("layernorm", float(M * d * (x.element_size() + out.element_size())), lambda: lib().pm_layernorm(
+        x.data_ptr(), x.stride(0), _dt(x), gamma.data_ptr(), beta.data_ptr(), float(eps),
+        out.data_ptr(), out.stride(0), _dt(out), M, d, _stream()))
     check(rc, f"pm_layernorm(M={M}, d={d})")
     return out
 
@@ -84,9 +102,10 @@ def attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = Fals
     for t in (q, k, v):
         _need(t.dtype == torch.bfloat16 and t.stride(2) == 1, "attention: bf16 operands with unit last stride")
     out = torch.empty((B, Lq, D), dtype=torch.bfloat16, device=q.device)
-    rc = lib().pm_attention_bf16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
-                                 v.data_ptr(), v.stride(0), v.stride(1), out.data_ptr(), out.stride(0), out.stride(1),
-                                 B, n_heads, Lq, Lk, int(causal), _stream())
+    rc = _launch("attention_bf16", 4.0 * B * n_heads * Lq * Lk * 64, lambda: lib().pm_attention_bf16(
+        q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+        v.data_ptr(), v.stride(0), v.stride(1), out.data_ptr(), out.stride(0), out.stride(1),
+        B, n_heads, Lq, Lk, int(causal), _stream()))
     check(rc, f"pm_attention_bf16(B={B}, H={n_heads}, Lq={Lq}, Lk={Lk})")
     return out
 
@@ -106,7 +125,8 @@ def vit_tokens(imgs: Tensor, w2d: Tensor, bias: Tensor, pe: Tensor, cls: Tensor 
     if cls is not None:
         _need(cls.dtype == torch.float32 and cls.numel() == d and cls.is_contiguous(), "vit_tokens: cls f32 (d)")
     out = torch.empty((N, L + (cls is not None), d), dtype=torch.bfloat16, device=imgs.device)
-    rc = lib().pm_vit_tokens(imgs.data_ptr(), w2d.data_ptr(), bias.data_ptr(), pe.data_ptr(),
-                             cls.data_ptr() if cls is not None else None, out.data_ptr(), N, H, W, patch, d, _stream())
+    rc = _launch("vit_tokens", float(imgs.numel() * 4 + out.numel() * 2), lambda: lib().pm_vit_tokens(
+        imgs.data_ptr(), w2d.data_ptr(), bias.data_ptr(), pe.data_ptr(),
+        cls.data_ptr() if cls is not None else None, out.data_ptr(), N, H, W, patch, d, _stream()))
     check(rc, f"pm_vit_tokens(N={N}, H={H}, W={W}, P={patch}, d={d})")
     return out
