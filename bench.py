@@ -27,6 +27,18 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 64)
+
+
 def vit_flops_per_image(n_layers=12, d=768, L=197, patches=196, k_patch=768) -> float:
     """n_layers * (24 L d^2 + 4 L^2 d) + 2 * patches * K * d."""
     return n_layers * (24 * L * d * d + 4 * L * L * d) + 2 * patches * k_patch * d
@@ -38,7 +50,7 @@ def cpu_baseline_vit(seconds_budget: float = 20.0) -> dict:
     from pytorch_models.image import ViT
     from synthweights import fill_module, synth_input
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     m = ViT.from_google("B/16")
     fill_module(m, 32)

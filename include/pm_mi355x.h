@@ -37,10 +37,22 @@ const char* pm_strerror(int code);
  * Replaces the four nn.Linear of MHA (transformer.py:28-31,47-49,53), MLP's linear1 -> act ->
  * linear2 (transformer.py:59-66) and the residual adds of Encoder/DecoderLayer (transformer.py:98-100,
  * 124-125).  x, w: bf16, K-contiguous; bias: f32 or NULL; resid: resid_dtype or NULL; y: y_dtype.
- * Requires K % 8 == 0, N % 4 == 0, ldy % 4 == 0, ldr % 4 == 0, 16-byte aligned x/w rows. */
+ * Requires K % 64 == 0 and 16-byte aligned x / w rows (ld % 8 == 0).  N, ldy, ldr multiples of 4 take the
+ * vector epilogue; ragged N (a 51865-row vocabulary: the tied-embedding logits of whisper.py:52) stores element-wise. */
 int pm_linear_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
                    const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype,
                    int64_t M, int64_t N, int64_t K, int act, void* stream);
+
+/* pm_linear_bf16 with two extra addressing features (everything else identical):
+ *  - x rows in two levels: row m lives at x + (m / x_rows_per_batch) * x_batch_stride + (m % x_rows_per_batch) * ldx
+ *    (x_rows_per_batch == 0: plain m * ldx).  With ldx = 2*d and K = 3*d over a zero-padded time-major buffer this
+ *    IS Conv1d(d, d, 3, stride 2, padding 1) (whisper.py:19): each output row reads 3 consecutive input rows;
+ *  - resid rows repeat every resid_period rows (0: no repeat), e.g. "+ pos_embs[:L]" broadcast over the batch
+ *    (whisper.py:31).  Order: y = act(x w^T + bias) + resid. */
+int pm_linear_bf16_ex(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
+                      int64_t ldw, const float* bias, const void* resid, int64_t ldr, int resid_dtype,
+                      int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
+                      void* stream);
 
 /* nn.LayerNorm over the last dim (transformer.py:87,90,93; vit.py:69; whisper.py:27,45):
  * y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta, fp32 statistics, biased variance.
@@ -67,6 +79,34 @@ int pm_attention_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t,
  * (SURVEY.md F1).  Requires P % 2 == 0... see pm_strerror for the exact supported set. */
 int pm_vit_tokens(const float* imgs, const void* w, const float* bias, const float* pe, const float* cls,
                   void* out, int64_t N, int64_t Himg, int64_t Wimg, int64_t P, int64_t d, void* stream);
+
+/* torch.stft(n_fft, hop, hann window, center=True, reflect, onesided).abs().square() (spectrogram.py:16),
+ * optionally followed by the mel filterbank (spectrogram.py:45) and Whisper's log10 (whisper.py:144-145).
+ * x: f32, clip b at x + b * x_stride, T samples.  tw_cos / tw_sin: f32 twiddle tables with the window folded in,
+ * laid out [ceil(nbins / 32)][n_fft / 2][64]: entry (blk, s, lane) = w[k] * cos|sin(2 pi k bin / n_fft) with
+ * k = 2 s + (lane >> 5), bin = 32 blk + (lane & 31) (0 for bin >= nbins).  n_frames <= 1 + T / hop frames are
+ * produced (Whisper drops the last one).  mode 0: out (B, n_fft/2+1, n_frames) power; mode 1: out
+ * (B, n_mels, n_frames) mel power, the filterbank given in CSR form (mel_ptr[n_mels+1], mel_col, mel_val);
+ * mode 2: log10 of mode 1 and peak[b] = order-preserving int encoding of the per-clip maximum (for
+ * pm_logmel_finalize).  n_fft, hop even; T > n_fft / 2. */
+int pm_stft_mel(const float* x, int64_t x_stride, int64_t B, int64_t T, const float* tw_cos, const float* tw_sin,
+                int64_t n_fft, int64_t hop, int64_t n_frames, int mode, const int32_t* mel_ptr, const int32_t* mel_col,
+                const float* mel_val, int64_t n_mels, float* out, int32_t* peak, void* stream);
+
+/* whisper.py:146-147 in place: out = (max(out, per-clip max - 8) + 4) / 4; per_clip = n_mels * n_frames (% 4 == 0). */
+int pm_logmel_finalize(float* out, const int32_t* peak, int64_t B, int64_t per_clip, void* stream);
+
+/* First stem conv of WhisperEncoder (whisper.py:17-18): Conv1d(C, d, 3, 1, 1) + GELU on channel-major f32
+ * x (B, C, T), written time-major bf16 as out (B, T + 2, d) with zero rows 0 and T + 1 (the padding the second,
+ * stride-2 conv needs: see pm_linear_bf16_ex).  w: bf16 (d, 3 * Cpad), K order (tap, channel), channels
+ * zero-padded to Cpad (% 64 == 0); bias f32 (d). */
+int pm_whisper_stem1(const float* x, const void* w, const float* bias, void* out, int64_t B, int64_t C, int64_t Cpad,
+                     int64_t T, int64_t d, void* stream);
+
+/* nn.Embedding + positional add (whisper.py:48-49): out[b, l, :] = emb[tokens[b, l], :] + pos[pos0 + l, :].
+ * tokens: int64 (B, L); emb: bf16 (V, d); pos: f32 (>= pos0 + L, d); out: bf16 | f32 (B, L, d). */
+int pm_embed_tokens(const int64_t* tokens, const void* emb, const float* pos, void* out, int out_dtype, int64_t B,
+                    int64_t L, int64_t pos0, int64_t d, int64_t V, void* stream);
 
 #ifdef __cplusplus
 }

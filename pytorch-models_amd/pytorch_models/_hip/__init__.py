@@ -24,6 +24,11 @@ SIGNATURES = {
     "pm_abi_version": ([], c_int),
     "pm_strerror": ([_i], c_char_p),
     "pm_linear_bf16": ([_p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
+    "pm_linear_bf16_ex": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
+    "pm_stft_mel": ([_p, _l, _l, _l, _p, _p, _l, _l, _l, _i, _p, _p, _p, _l, _p, _p, _p], c_int),
+    "pm_logmel_finalize": ([_p, _p, _l, _l, _p], c_int),
+    "pm_whisper_stem1": ([_p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
+    "pm_embed_tokens": ([_p, _p, _p, _p, _i, _l, _l, _l, _l, _l, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
     "pm_attention_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
     "pm_vit_tokens": ([_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),

@@ -130,3 +130,117 @@ def vit_tokens(imgs: Tensor, w2d: Tensor, bias: Tensor, pe: Tensor, cls: Tensor 
         cls.data_ptr() if cls is not None else None, out.data_ptr(), N, H, W, patch, d, _stream()))
     check(rc, f"pm_vit_tokens(N={N}, H={H}, W={W}, P={patch}, d={d})")
     return out
+
+
+def linear_strided(x: Tensor, *, M: int, K: int, row_stride: int, rows_per_batch: int, batch_stride: int, w: Tensor,
+                   bias: Tensor | None = None, act: str = "none", resid: Tensor | None = None, resid_period: int = 0,
+                   out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """pm_linear_bf16_ex: row m of the A operand is the K contiguous bf16 values at
+    x.flat[(m // rows_per_batch) * batch_stride + (m % rows_per_batch) * row_stride : ... + K] (rows may overlap:
+    that is how a strided conv window is expressed); resid rows repeat every resid_period rows."""
+    _cuda(x, w, bias, resid)
+    _need(x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.is_contiguous() and w.dim() == 2 and w.stride(1) == 1,
+          "linear_strided: contiguous bf16 x, K-contiguous bf16 w")
+    _need(w.shape[1] == K and rows_per_batch > 0 and M % rows_per_batch == 0, "linear_strided: bad geometry")
+    nb = M // rows_per_batch
+    last = (nb - 1) * batch_stride + (rows_per_batch - 1) * row_stride + K
+    _need(last <= x.numel(), f"linear_strided: window runs past the buffer ({last} > {x.numel()})")
+    N = w.shape[0]
+    if bias is not None:
+        _need(bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N, "linear_strided: bias f32 (N)")
+    if resid is not None:
+        _need(resid.dim() == 2 and resid.shape[1] == N and resid.stride(1) == 1, "linear_strided: resid (rows, N)")
+        _need(resid.shape[0] >= (resid_period or M), "linear_strided: resid has too few rows")
+    out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16_ex(
+        x.data_ptr(), row_stride, rows_per_batch, batch_stride, w.data_ptr(), w.stride(0),
+        bias.data_ptr() if bias is not None else None, resid.data_ptr() if resid is not None else None,
+        resid.stride(0) if resid is not None else 0, _dt(resid) if resid is not None else 0, resid_period,
+        out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream()))
+    check(rc, f"pm_linear_bf16_ex(M={M}, N={N}, K={K})")
+    return out
+
+
+def stft_tables(window: Tensor, n_fft: int) -> tuple[Tensor, Tensor]:
+    """Twiddle tables of pm_stft_mel (window folded in), built in float64 on the host, laid out
+    [ceil(nbins / 32)][n_fft / 2][64] (see include/pm_mi355x.h)."""
+    nbins = n_fft // 2 + 1
+    nblk = (nbins + 31) // 32
+    k = torch.arange(n_fft, dtype=torch.float64)
+    b = torch.arange(nblk * 32, dtype=torch.float64)
+    ang = 2.0 * torch.pi * torch.outer(k, b) / n_fft
+    w = window.detach().double().cpu()[:, None]
+    valid = (b < nbins)[None, :]
+    out = []
+    for tab in (torch.cos(ang), torch.sin(ang)):
+        tab = (tab * w * valid).float()  # (n_fft, nblk * 32)
+        tab = tab.view(n_fft // 2, 2, nblk, 32).permute(2, 0, 1, 3).contiguous().view(-1)
+        out.append(tab.to(window.device))
+    return out[0], out[1]
+
+
+def mel_csr(filters: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """CSR form (int32 row pointers, int32 columns, f32 values) of a dense (n_mels, nbins) filterbank."""
+    f = filters.detach().float().cpu()
+    nz = f != 0
+    ptr = torch.zeros(f.shape[0] + 1, dtype=torch.int32)
+    ptr[1:] = nz.sum(1).cumsum(0)
+    rows, cols = nz.nonzero(as_tuple=True)
+    dev = filters.device
+    return ptr.to(dev), cols.to(torch.int32).to(dev), f[rows, cols].contiguous().to(dev)
+
+
+def stft_mel(x: Tensor, tables, n_fft: int, hop: int, n_frames: int, mode: int, csr=None, n_mels: int = 0) -> Tensor:
+    """x (..., T) f32 -> mode 0: (..., n_fft/2+1, n_frames) power; 1: (..., n_mels, n_frames) mel power;
+    2: Whisper log-mel (log10, per-clip max - 8 floor, (x + 4) / 4) via pm_stft_mel + pm_logmel_finalize."""
+    _cuda(x, tables[0])
+    lead, T = x.shape[:-1], x.shape[-1]
+    x2 = x.reshape(-1, T).float().contiguous()
+    B = x2.shape[0]
+    rows = n_fft // 2 + 1 if mode == 0 else n_mels
+    out = torch.empty((B, rows, n_frames), dtype=torch.float32, device=x.device)
+    peak = torch.empty(max(B, 1), dtype=torch.int32, device=x.device) if mode == 2 else None
+    ptr, col, val = csr if csr is not None else (None, None, None)
+    rc = _launch("stft_mel", float(x2.numel() * 4 + out.numel() * 4), lambda: lib().pm_stft_mel(
+        x2.data_ptr(), T, B, T, tables[0].data_ptr(), tables[1].data_ptr(), n_fft, hop, n_frames, mode,
+        ptr.data_ptr() if ptr is not None else None, col.data_ptr() if col is not None else None,
+        val.data_ptr() if val is not None else None, n_mels, out.data_ptr(), peak.data_ptr() if peak is not None else None,
+        _stream()))
+    check(rc, f"pm_stft_mel(B={B}, T={T}, n_fft={n_fft}, hop={hop}, mode={mode})")
+    if mode == 2:
+        rc = _launch("logmel_finalize", float(out.numel() * 8), lambda: lib().pm_logmel_finalize(
+            out.data_ptr(), peak.data_ptr(), B, rows * n_frames, _stream()))
+        check(rc, "pm_logmel_finalize")
+    return out.view(*lead, rows, n_frames)
+
+
+def whisper_stem1(x: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
+    """x f32 (B, C, T) channel-major -> bf16 (B, T + 2, d) time-major, GELU(conv1d k3 s1 p1), zero rows 0 and T+1."""
+    _cuda(x, w1, b1)
+    _need(x.dim() == 3 and x.dtype == torch.float32 and x.is_contiguous(), "whisper_stem1: x must be contiguous f32 (B, C, T)")
+    B, C, T = x.shape
+    d, K = w1.shape
+    _need(w1.dtype == torch.bfloat16 and w1.is_contiguous() and K % 3 == 0 and K // 3 >= C, "whisper_stem1: bad packed weight")
+    _need(b1.dtype == torch.float32 and b1.numel() == d, "whisper_stem1: bias f32 (d)")
+    out = torch.empty((B, T + 2, d), dtype=torch.bfloat16, device=x.device)
+    rc = _launch("whisper_stem1", float(x.numel() * 4 + out.numel() * 2), lambda: lib().pm_whisper_stem1(
+        x.data_ptr(), w1.data_ptr(), b1.data_ptr(), out.data_ptr(), B, C, K // 3, T, d, _stream()))
+    check(rc, f"pm_whisper_stem1(B={B}, C={C}, T={T}, d={d})")
+    return out
+
+
+def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor, pos0: int = 0, out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """tokens int64 (B, L) -> (B, L, d): emb[tokens] + pos[pos0 : pos0 + L]."""
+    _cuda(tokens, emb, pos)
+    _need(tokens.dim() == 2 and tokens.dtype == torch.int64, "embed_tokens: tokens must be int64 (B, L)")
+    tokens = tokens.contiguous()
+    B, L = tokens.shape
+    V, d = emb.shape
+    _need(emb.dtype == torch.bfloat16 and emb.is_contiguous(), "embed_tokens: emb bf16 (V, d)")
+    _need(pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == d and pos.shape[0] >= pos0 + L,
+          f"embed_tokens: need {pos0 + L} position rows, have {pos.shape[0]}")
+    out = torch.empty((B, L, d), dtype=out_dtype, device=emb.device)
+    rc = lib().pm_embed_tokens(tokens.data_ptr(), emb.data_ptr(), pos.data_ptr(), out.data_ptr(), _dt(out), B, L, pos0, d, V,
+                               _stream())
+    check(rc, f"pm_embed_tokens(B={B}, L={L}, d={d})")
+    return out

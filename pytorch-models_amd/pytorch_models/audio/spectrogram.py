@@ -13,6 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from .._hip import ops
+from ..transformer import derived
 
 
 def get_mel_filters(n_mels: int, n_fft: int, sample_rate: float) -> Tensor:
@@ -40,9 +41,12 @@ class Spectrogram(nn.Module):
         self.register_buffer("window", torch.hann_window(n_fft), False)
         self.window: Tensor
 
+    def _tables(self):
+        return derived(self, "tw", (self.window,), lambda: ops.stft_tables(self.window, self.n_fft))
+
     def forward(self, x: Tensor) -> Tensor:
         """(..., T) -> (..., n_fft/2+1, 1 + T // hop) power spectrogram (center=True, reflect padding)."""
-        return ops.stft_power(x, self.window, self.n_fft, self.hop_length)
+        return ops.stft_mel(x, self._tables(), self.n_fft, self.hop_length, 1 + x.shape[-1] // self.hop_length, 0)
 
 
 class MelSpectrogram(Spectrogram):
@@ -51,5 +55,9 @@ class MelSpectrogram(Spectrogram):
         self.register_buffer("filters", get_mel_filters(n_mels, n_fft, sample_rate))
         self.filters: Tensor
 
+    def _csr(self):
+        return derived(self, "csr", (self.filters,), lambda: ops.mel_csr(self.filters))
+
     def forward(self, x: Tensor) -> Tensor:
-        return ops.mel_power(x, self.window, self.filters, self.n_fft, self.hop_length, drop_last=False)
+        return ops.stft_mel(x, self._tables(), self.n_fft, self.hop_length, 1 + x.shape[-1] // self.hop_length, 1,
+                            self._csr(), self.filters.shape[0])

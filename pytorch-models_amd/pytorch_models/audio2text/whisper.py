@@ -61,8 +61,9 @@ class WhisperEncoder(nn.Module):
         y1 = ops.whisper_stem1(x.float().contiguous(), w1, b1)  # (B, T + 2, d) bf16, rows 0 and T + 1 zero
         L = (T - 1) // 2 + 1
         pos = _f32(self, "pos", self.pos_embs)[:L]
-        y2 = ops.linear(y1.view(B * (T + 2), d), w2, b2, act="gelu", resid=pos, resid_period=L,
-                        x_rows_per_batch=L, x_batch_stride=(T + 2) * d, x_row_stride=2 * d, k=3 * d, m=B * L)
+        # Conv1d(d, d, 3, stride 2, pad 1): output row t' reads buffer rows 2t', 2t'+1, 2t'+2 = 3*d contiguous values
+        y2 = ops.linear_strided(y1, M=B * L, K=3 * d, row_stride=2 * d, rows_per_batch=L, batch_stride=(T + 2) * d,
+                                w=w2, bias=b2, act="gelu", resid=pos, resid_period=L)
         return self.norm(self.layers(y2.view(B, L, d)))
 
 
@@ -83,7 +84,7 @@ class WhisperDecoder(nn.Module):
             raise NotImplementedError("WhisperDecoder: only the bf16 path is built; use model.to(torch.bfloat16)")
         h = ops.embed_tokens(x, E, _f32(self, "pos", self.pos_embs))  # (B, L, d) bf16
         h = self.norm(self.layers(h, memory))
-        return ops.logits(h.view(-1, h.shape[-1]), E).view(*x.shape, E.shape[0])
+        return ops.linear(h.view(-1, h.shape[-1]), E, None, out_dtype=torch.float32).view(*x.shape, E.shape[0])
 
 
 class Whisper(nn.Module):
@@ -118,4 +119,4 @@ class WhisperPreprocessor(MelSpectrogram):
     def forward(self, x: Tensor) -> Tensor:
         """(..., T) waveform -> (..., n_mels, T // 160) log-mel: last frame dropped, log10, floored at the
         PER-SAMPLE max - 8, (x + 4) / 4 - all inside the two logmel kernels."""
-        return ops.whisper_logmel(x, self.window, self.filters)
+        return ops.stft_mel(x, self._tables(), 400, 160, x.shape[-1] // 160, 2, self._csr(), self.filters.shape[0])

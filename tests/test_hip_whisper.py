@@ -1,0 +1,141 @@
+"""GPU parity of the Whisper path (front end, encoder, teacher-forced decoder) against the oracle and the
+reference's golden vectors.
+
+Tolerances (stated):
+* STFT power / mel / log-mel run in exact fp32 (f32 MFMA = an fp32 FMA chain): they must meet the reference's own
+  tolerance vs the oracle: rtol 2e-5 with atol scaled to the value range (spectrogram.py tests use 2e-5/2e-5 on
+  O(1) data; log-mel uses atol 2e-5 on the (x+4)/4 scale... we allow 1e-4 where log10 amplifies tiny bins).
+* encoder / decoder (bf16 activations, fp32 accumulate) vs the fp32 oracle on bf16-rounded weights:
+  rel-L2 <= 2e-2 on LayerNorm-ed outputs, logits rel-L2 <= 3e-2.
+"""
+import pytest
+import torch
+
+from oracle import ref_spectrogram as RS
+from oracle import ref_whisper as RW
+from synthweights import bf16_round_, fill_module, synth_input, synth_tokens
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def rel_l2(got, want):
+    got, want = got.float().cpu(), want.float()
+    return ((got - want).norm() / want.norm()).item()
+
+
+# ---------------------------------------------------------------- front end (exact fp32)
+def test_spectrogram_and_mel_1s(golden):
+    from pytorch_models.audio.spectrogram import MelSpectrogram, Spectrogram
+
+    g = golden("audio")
+    x1 = synth_input("wave_1s", (16000,), 41)
+    spec = Spectrogram(400, 160).cuda()(x1.cuda()).cpu()
+    assert spec.shape == (201, 101)
+    torch.testing.assert_close(spec, RS.power_spectrogram(x1, 400, 160), rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(spec, g["spec_1s"], rtol=2e-5, atol=2e-4)
+    mel = MelSpectrogram(400, 160, 80, 16000).cuda()(x1.cuda()).cpu()
+    torch.testing.assert_close(mel, g["mel_1s"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("variant,key", [("tiny", "logmel_1s"), ("large-v3", "logmel128_1s")])
+def test_logmel_1s(golden, variant, key):
+    from pytorch_models.audio2text import WhisperPreprocessor
+
+    x1 = synth_input("wave_1s", (16000,), 41)
+    got = WhisperPreprocessor(variant).cuda()(x1.cuda()).cpu()
+    want = golden("audio")[key]
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(got, RS.whisper_log_mel(x1, want.shape[0]), rtol=1e-5, atol=2e-5)
+
+
+def test_logmel_30s_batch_and_edges(golden):
+    from pytorch_models.audio2text import WhisperPreprocessor
+
+    g = golden("audio")
+    pre = WhisperPreprocessor("base").cuda()
+    x30 = synth_input("wave_30s", (2, 480000), 42, scale=0.1)
+    lm = pre(x30.cuda()).cpu()
+    assert lm.shape == (2, 80, 3000)
+    torch.testing.assert_close(lm[:, ::8, ::100], g["logmel_30s_slice"], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(lm[0, :, :8], g["logmel_30s_head"], rtol=1e-5, atol=2e-5)  # reflect padding at the start
+    torch.testing.assert_close(lm[1, :, -8:], g["logmel_30s_tail"], rtol=1e-5, atol=2e-5)  # ... and at the end
+    torch.testing.assert_close(lm, RS.whisper_log_mel(x30, 80, "rfft"), rtol=1e-5, atol=3e-5)
+    # per-sample max (reference tests/audio2text/test_whisper.py:57-65)
+    xb = synth_input("wave_batch", (4, 16000), 43)
+    xb[0] += 0.5
+    got = pre(xb.cuda())
+    torch.testing.assert_close(got.cpu(), g["logmel_batch"], rtol=1e-5, atol=2e-5)
+    one = torch.stack([pre(xb[i].cuda()) for i in range(4)])
+    torch.testing.assert_close(got, one, rtol=0, atol=0)
+    # half-silent clip: exact zeros in the tail -> log10(0) = -inf -> floored at max - 8
+    xs = synth_input("wave_half_silent", (16000,), 44)
+    xs[8000:] = 0
+    torch.testing.assert_close(pre(xs.cuda()).cpu(), g["logmel_half_silent"], rtol=1e-5, atol=2e-5)
+    # leading dims are kept
+    assert pre(xb.view(2, 2, 16000).cuda()).shape == (2, 2, 80, 100)
+
+
+def test_logmel_full_size_batch32_properties():
+    """BASELINE config[2] front end at full size (32 x 30 s): finite, max per clip == 1.5 + ..., batch-invariant."""
+    from pytorch_models.audio2text import WhisperPreprocessor
+
+    pre = WhisperPreprocessor("base").cuda()
+    x = synth_input("wave_full", (32, 480000), 45, scale=0.1).cuda()
+    out = pre(x)
+    assert out.shape == (32, 80, 3000) and torch.isfinite(out).all()
+    # by construction min >= (max - 8 + 4) / 4 per clip
+    mx = out.flatten(1).max(1).values
+    mn = out.flatten(1).min(1).values
+    assert (mn >= mx - 2.0 - 1e-6).all()
+    torch.testing.assert_close(out[5], pre(x[5]), rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------- encoder / decoder (bf16)
+def hip_and_sd(m, seed):
+    fill_module(m, seed)
+    bf16_round_(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    return m.to(torch.bfloat16).cuda().eval(), sd
+
+
+def test_whisper_smoke_shapes(golden):
+    """The reference's smoke shapes (tests/audio2text/test_whisper.py:10-24): vocab 100, 2 layers, d = 64."""
+    from pytorch_models.audio2text import Whisper, WhisperDecoder, WhisperEncoder
+
+    g = golden("whisper")
+    vocab, L, d = 100, 2, 64
+    mel = synth_input("w_mel16", (2, 80, 16), 51)
+    toks = synth_tokens("w_tok32", (2, 32), vocab, 52)
+    enc, sd = hip_and_sd(WhisperEncoder(L, d), 51)
+    got = enc(mel.cuda())
+    assert got.shape == (2, 8, d)
+    assert rel_l2(got, RW.encoder(sd, "", mel)) < 2e-2 and rel_l2(got, g["smoke_encoder"]) < 2e-2
+    dec, sd = hip_and_sd(WhisperDecoder(vocab, L, d), 52)
+    mem = synth_input("w_mem16", (2, 16, d), 52)
+    got = dec(toks.cuda(), mem.to(torch.bfloat16).cuda())
+    assert got.shape == (2, 32, vocab) and got.dtype == torch.float32
+    assert rel_l2(got, RW.decoder(sd, "", toks, mem.to(torch.bfloat16).float())) < 3e-2
+    w, sd = hip_and_sd(Whisper(vocab, L, d), 53)
+    got = w(mel.cuda(), toks.cuda())
+    assert rel_l2(got, RW.forward(sd, mel, toks)) < 3e-2 and rel_l2(got, g["smoke_whisper"]) < 3e-2
+
+
+def test_whisper_tiny_reference_test_shape(golden):
+    """The reference's pretrained-parity shape (test_whisper.py:39-42): mel (1, 80, 3000), tokens (1, 32) < 200."""
+    from pytorch_models.audio2text import Whisper
+
+    g = golden("whisper")
+    w, sd = hip_and_sd(Whisper.from_openai("tiny"), 54)
+    mel = synth_input("w_mel3000", (1, 80, 3000), 54)
+    toks = synth_tokens("w_tok200", (1, 32), 200, 54)
+    memory = w.encoder(mel.cuda())
+    assert memory.shape == (1, 1500, 384)
+    assert rel_l2(memory[0, ::100, ::32], g["tiny_memory_slice"]) < 2e-2
+    assert rel_l2(memory, RW.encoder(sd, "encoder.", mel)) < 2e-2
+    logits = w.decoder(toks.cuda(), memory)
+    assert logits.shape == (1, 32, 51865)
+    assert rel_l2(logits[0, :, :128], g["tiny_logits_slice"]) < 3e-2
+    want = RW.decoder(sd, "decoder.", toks, memory.float().cpu())  # same memory -> isolates the decoder
+    assert rel_l2(logits, want) < 3e-2
