@@ -108,6 +108,40 @@ int pm_whisper_stem1(const float* x, const void* w, const float* bias, void* out
 int pm_embed_tokens(const int64_t* tokens, const void* emb, const float* pos, void* out, int out_dtype, int64_t B,
                     int64_t L, int64_t pos0, int64_t d, int64_t V, void* stream);
 
+/* ---- KV-cached greedy decode step (no reference counterpart: README.md:86 lists Whisper decoding as TODO; the
+ * semantics follow pytorch_models/text/generator.py:23-35 over transformer.py:96-100 and whisper.py:47-53).
+ * All activations f32, weights / caches bf16.  `pos_ptr` points at ONE device int: the position t of the token being
+ * consumed; every kernel of a step reads it, pm_dec_advance increments it, so one captured graph replays all steps. */
+
+/* x[b, :] = emb[tok_cur[b], :] + pos[t, :]  (whisper.py:48-49 for one position). */
+int pm_dec_embed(const int64_t* tok_cur, const void* emb, const float* pos, const int32_t* pos_ptr, float* x, int64_t B,
+                 int64_t d, int64_t V, void* stream);
+
+/* y = act([LayerNorm_{gamma,beta,eps}](x) w^T + bias) [+ resid] for M <= 64 rows of f32 x; w bf16 (N, K).
+ * gamma == NULL: no LayerNorm.  mode 0: out f32 (M, N) (+ resid f32, may alias out);
+ * mode 1 (N = 3*inner, [q|k|v] blocks): q -> out f32 (M, inner); k, v -> bf16 caches (M, H, Tmax, 64) at position t;
+ * mode 2: no store - per row, the tile's (max logit, lowest index) go to ws_val / ws_idx (M, ceil(N/16)).
+ * act: PM_ACT_NONE | PM_ACT_GELU (erff).  K % 32 == 0. */
+int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w,
+                  int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M,
+                  int64_t N, int64_t K, int act, int mode, void* kcache, void* vcache, int64_t inner, int64_t H,
+                  int64_t Tmax, const int32_t* pos_ptr, float* ws_val, int32_t* ws_idx, void* stream);
+
+/* One query per (sequence, head), head_dim 64: out = softmax(q K^T / 8) V (transformer.py:52 with L_q = 1 and NO
+ * causal flag - SURVEY.md F3).  q / out f32 (B, H*64); K/V bf16 addressed base + b*stride_b + h*stride_h + key*stride_k;
+ * number of keys = (lk_ptr ? *lk_ptr : 0) + lk_add  (self: pos + 1; cross: the constant 1500), <= lk_max <= 4096. */
+int pm_dec_attention(const float* q, const void* kc, const void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
+                     const int32_t* lk_ptr, int64_t lk_add, int64_t lk_max, float* out, int64_t B, int64_t H, void* stream);
+
+/* Finish the argmax over the n_tiles tile winners of pm_dec_linear mode 2 (lowest index on ties, like torch.argmax),
+ * teacher-force the prompt (next = prompt[b, t+1] while t + 1 < P), write tok_cur[b] and tokens_out[b, t+1]. */
+int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_tiles, const int32_t* pos_ptr,
+                         const int64_t* prompt, int64_t P, int64_t* tok_cur, int64_t* tokens_out, int64_t Ttot,
+                         float* margin_out, int64_t B, void* stream);
+
+/* ++*pos_ptr, as its own launch (every workgroup of the step has read t by then). */
+int pm_dec_advance(int32_t* pos_ptr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,11 @@ SIGNATURES = {
     "pm_logmel_finalize": ([_p, _p, _l, _l, _p], c_int),
     "pm_whisper_stem1": ([_p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_embed_tokens": ([_p, _p, _p, _p, _i, _l, _l, _l, _l, _l, _p], c_int),
+    "pm_dec_embed": ([_p, _p, _p, _p, _p, _l, _l, _l, _p], c_int),
+    "pm_dec_linear": ([_p, _l, _p, _p, _f, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _p, _p, _l, _l, _l, _p, _p, _p, _p], c_int),
+    "pm_dec_attention": ([_p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _p], c_int),
+    "pm_dec_argmax_reduce": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _l, _p], c_int),
+    "pm_dec_advance": ([_p, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
     "pm_attention_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
     "pm_vit_tokens": ([_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),

@@ -244,3 +244,49 @@ def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor, pos0: int = 0, out_dt
                                _stream())
     check(rc, f"pm_embed_tokens(B={B}, L={L}, d={d})")
     return out
+
+
+# ---- decode-step kernels as standalone ops (the generator builds raw launch lists; these wrappers serve tests) ----
+def dec_linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, ln: tuple | None = None, act: str = "none",
+               resid: Tensor | None = None) -> Tensor:
+    """y = act(LN?(x) @ w.T + bias) + resid for <= 64 rows of f32 x and bf16 w (fp32-exact: bf16x3 split)."""
+    _cuda(x, w, bias, resid)
+    _need(x.dtype == torch.float32 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2, "dec_linear: f32 x, bf16 w")
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    rc = lib().pm_dec_linear(x.data_ptr(), x.stride(0), g.data_ptr() if g is not None else None,
+                             b.data_ptr() if b is not None else None, float(eps), w.data_ptr(), w.stride(0),
+                             bias.data_ptr() if bias is not None else None, resid.data_ptr() if resid is not None else None,
+                             resid.stride(0) if resid is not None else 0, out.data_ptr(), out.stride(0), M, N, K, ACT[act], 0,
+                             None, None, 0, 0, 0, None, None, None, _stream())
+    check(rc, f"pm_dec_linear(M={M}, N={N}, K={K})")
+    return out
+
+
+def dec_argmax(x: Tensor, w: Tensor, ln: tuple) -> tuple[Tensor, Tensor]:
+    """Per-row argmax (and max) of LN(x) @ w.T without materialising the logits."""
+    M, K = x.shape
+    N = w.shape[0]
+    nt = (N + 15) // 16
+    wv = torch.empty(M, nt, dtype=torch.float32, device=x.device)
+    wi = torch.empty(M, nt, dtype=torch.int32, device=x.device)
+    g, b, eps = ln
+    rc = lib().pm_dec_linear(x.data_ptr(), x.stride(0), g.data_ptr(), b.data_ptr(), float(eps), w.data_ptr(), w.stride(0), None,
+                             None, 0, None, 0, M, N, K, 0, 2, None, None, 0, 0, 0, None, wv.data_ptr(), wi.data_ptr(), _stream())
+    check(rc, "pm_dec_linear(argmax)")
+    best = wv.max(1)
+    cand = torch.where(wv == best.values[:, None], wi, torch.full_like(wi, 2**31 - 1))
+    return cand.min(1).values.long(), best.values
+
+
+def dec_attention(q: Tensor, k: Tensor, v: Tensor, lk: int) -> Tensor:
+    """q f32 (B, H*64); k, v bf16 (B, H, T, 64) caches; attends over the first lk keys."""
+    _cuda(q, k, v)
+    B, H, T, _ = k.shape
+    out = torch.empty_like(q)
+    rc = lib().pm_dec_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), k.stride(1), k.stride(2), None, lk, T,
+                                out.data_ptr(), B, H, _stream())
+    check(rc, "pm_dec_attention")
+    return out

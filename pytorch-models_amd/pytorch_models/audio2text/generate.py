@@ -1,0 +1,162 @@
+"""Batched greedy decoding with a KV cache for WhisperDecoder on MI355X.
+
+New capability (the reference decodes nothing for Whisper: README.md:86).  Semantics = the reference's
+generic greedy loop (text/generator.py:23-35): at each step take argmax of the last position's logits and
+append it; here for a whole batch, with the self-attention K/V cached and the cross-attention K/V projected
+once.  The stop rule is build-defined (no tokenizer in the reference): a fixed number of new tokens.
+
+One step is ~8 launches per layer (csrc/decode.hip); the position and current tokens live on the device, so the
+step is captured ONCE into a HIP graph and replayed - no tracing compiler, no host round trips in the loop.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .._hip import check, lib, ops
+from ..transformer import _f32
+
+
+def _ptr(t: Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+class GreedyDecoder:
+    """State + launch list of the decode step for one (decoder, batch, memory length) geometry."""
+
+    def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False) -> None:
+        E = dec.token_embs.weight
+        if E.dtype != torch.bfloat16 or not E.is_cuda:
+            raise NotImplementedError("greedy decode: bf16 weights on a HIP device only (model.to(torch.bfloat16).cuda())")
+        if memory.dtype != torch.bfloat16 or memory.dim() != 3:
+            raise ValueError("greedy decode: memory must be the encoder's bf16 (B, S, d) output")
+        B, S, d = memory.shape
+        P = prompt.shape[1]
+        if prompt.shape[0] != B or prompt.dtype != torch.int64 or P < 1:
+            raise ValueError("greedy decode: prompt must be int64 (B, P >= 1)")
+        V = E.shape[0]
+        if int(prompt.min()) < 0 or int(prompt.max()) >= V:
+            raise ValueError("greedy decode: prompt ids out of range")
+        self.Ttot = P + n_new
+        if self.Ttot > dec.pos_embs.shape[0]:
+            raise ValueError(f"greedy decode: {self.Ttot} positions > max_seq_len {dec.pos_embs.shape[0]}")
+        if B > 64:
+            raise NotImplementedError("greedy decode: at most 64 sequences per call (shard larger batches)")
+        dev = memory.device
+        H = dec.layers[0].sa.n_heads
+        inner = H * 64
+        if dec.layers[0].sa.head_dim != 64 or inner != d:
+            raise NotImplementedError("greedy decode: head_dim 64 with n_heads * 64 == d_model only")
+        self.B, self.P, self.n_steps = B, P, self.Ttot - 1
+        Tmax = self.Ttot
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x = torch.empty(B, d, **f32)
+        self.q = torch.empty(B, inner, **f32)
+        self.att = torch.empty(B, inner, **f32)
+        self.h = torch.empty(B, 4 * d, **f32)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.prompt = prompt.contiguous().to(dev)
+        self.tok_cur = self.prompt[:, 0].clone()
+        self.tokens = torch.zeros(B, self.Ttot, dtype=torch.int64, device=dev)
+        self.tokens[:, :P] = self.prompt
+        self.margins = torch.zeros(B, self.Ttot, **f32) if margins else None
+        n_tiles = (V + 15) // 16
+        self.ws_val = torch.empty(B, n_tiles, **f32)
+        self.ws_idx = torch.empty(B, n_tiles, dtype=torch.int32, device=dev)
+        pos_f32 = _f32(dec, "pos", dec.pos_embs)
+        mem2 = memory.reshape(B * S, d)
+        L = lib()
+        self._keep = [E, pos_f32, memory]  # tensors the launch list points into
+        self.launches = []  # (fn, args): raw pointers only -> the loop has no per-step Python work beyond ctypes
+
+        def add(fn, *args):
+            self.launches.append((fn, args))
+
+        def dec_linear(x, K, gamma, beta, eps, w, bias, resid, out, N, act=0, mode=0, kc=None, vc=None, ldo=None):
+            self._keep += [w, bias, gamma, beta]
+            add(L.pm_dec_linear, x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), w.data_ptr(), w.stride(0),
+                _ptr(bias), _ptr(resid), resid.stride(0) if resid is not None else 0, _ptr(out),
+                (out.stride(0) if out is not None else 0) if ldo is None else ldo, B, N, K, act, mode, _ptr(kc), _ptr(vc),
+                inner, H, Tmax, self.pos.data_ptr(), self.ws_val.data_ptr(), self.ws_idx.data_ptr(), None)
+
+        add(L.pm_dec_embed, self.tok_cur.data_ptr(), E.data_ptr(), pos_f32.data_ptr(), self.pos.data_ptr(), self.x.data_ptr(),
+            B, d, V, None)
+        self.self_k, self.self_v, self.cross_kv = [], [], []
+        for layer in dec.layers:
+            if not layer.pre_norm or layer.ca is None:
+                raise NotImplementedError("greedy decode: pre-norm layers with cross-attention only")
+            sa, ca, mlp = layer.sa, layer.ca, layer.mlp
+            kc = torch.empty(B, H, Tmax, 64, dtype=torch.bfloat16, device=dev)
+            vc = torch.empty_like(kc)
+            self.self_k.append(kc)
+            self.self_v.append(vc)
+            wqkv, bqkv = sa._pack("qkv")
+            g, b = _f32(layer.sa_norm, "g", layer.sa_norm.weight), _f32(layer.sa_norm, "b", layer.sa_norm.bias)
+            dec_linear(self.x, d, g, b, layer.sa_norm.eps, wqkv, bqkv, None, self.q, 3 * inner, mode=1, kc=kc, vc=vc)
+            add(L.pm_dec_attention, self.q.data_ptr(), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64,
+                self.pos.data_ptr(), 1, Tmax, self.att.data_ptr(), B, H, None)
+            dec_linear(self.att, inner, None, None, 0.0, sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), self.x,
+                       self.x, d)
+            # cross attention: K/V of the memory projected ONCE (the reference re-projects them on every call,
+            # transformer.py:44-49), kept packed (B, S, [k | v]) in bf16
+            wkv, bkv = ca._pack("kv")
+            kv = ops.linear(mem2, wkv, bkv)
+            self.cross_kv.append(kv)
+            g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
+            dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, _f32(ca.q_proj, "b", ca.q_proj.bias), None, self.q,
+                       inner)
+            add(L.pm_dec_attention, self.q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64, 2 * inner,
+                None, S, S, self.att.data_ptr(), B, H, None)
+            dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), self.x,
+                       self.x, d)
+            g, b = _f32(layer.mlp_norm, "g", layer.mlp_norm.weight), _f32(layer.mlp_norm, "b", layer.mlp_norm.bias)
+            if mlp.act_name != "gelu":
+                raise NotImplementedError("greedy decode: GELU MLP only")
+            hid = mlp.linear1.out_features
+            dec_linear(self.x, d, g, b, layer.mlp_norm.eps, mlp.linear1.weight, _f32(mlp.linear1, "b", mlp.linear1.bias), None,
+                       self.h[:, :hid], hid, act=1)
+            dec_linear(self.h[:, :hid], hid, None, None, 0.0, mlp.linear2.weight, _f32(mlp.linear2, "b", mlp.linear2.bias),
+                       self.x, self.x, d)
+        g, b = _f32(dec.norm, "g", dec.norm.weight), _f32(dec.norm, "b", dec.norm.bias)
+        dec_linear(self.x, d, g, b, dec.norm.eps, E, None, None, None, V, mode=2, ldo=0)
+        add(L.pm_dec_argmax_reduce, self.ws_val.data_ptr(), self.ws_idx.data_ptr(), n_tiles, self.pos.data_ptr(),
+            self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot, _ptr(self.margins), B, None)
+        add(L.pm_dec_advance, self.pos.data_ptr(), None)
+
+    def step(self) -> None:
+        st = torch.cuda.current_stream().cuda_stream
+        for fn, args in self.launches:
+            rc = fn(*args[:-1], st)
+            if rc:
+                check(rc, fn.__name__)
+
+    def reset(self) -> None:
+        self.pos.zero_()
+        self.tok_cur.copy_(self.prompt[:, 0])
+
+    def run(self, graph: bool = True) -> Tensor:
+        if not graph:
+            self.reset()
+            for _ in range(self.n_steps):
+                self.step()
+            return self.tokens
+        if getattr(self, "_graph", None) is None:
+            self.reset()
+            self.step()  # eager warm-up: loads every kernel before capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self._graph = g
+        self.reset()
+        for _ in range(self.n_steps):
+            self._graph.replay()
+        return self.tokens
+
+
+@torch.no_grad()
+def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: bool = True, margins: bool = False):
+    """tokens (B, P + n_new) int64 [and per-position diagnostic margins]."""
+    st = GreedyDecoder(dec, memory, prompt, n_new, margins)
+    toks = st.run(graph)
+    return (toks, st.margins) if margins else toks

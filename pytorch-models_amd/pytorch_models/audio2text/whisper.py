@@ -86,6 +86,13 @@ class WhisperDecoder(nn.Module):
         h = self.norm(self.layers(h, memory))
         return ops.linear(h.view(-1, h.shape[-1]), E, None, out_dtype=torch.float32).view(*x.shape, E.shape[0])
 
+    @torch.no_grad()
+    def generate(self, memory: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True) -> Tensor:
+        """Batched greedy decoding with a KV cache: (B, P) int64 prompt -> (B, P + max_new_tokens) ids."""
+        from .generate import greedy_decode
+
+        return greedy_decode(self, memory, prompt, max_new_tokens, graph=graph)
+
 
 class Whisper(nn.Module):
     def __init__(self, vocab_size: int, n_layers: int, d_model: int, n_mels: int = 80, dropout: float = 0.0) -> None:
@@ -95,6 +102,11 @@ class Whisper(nn.Module):
 
     def forward(self, x: Tensor, targets: Tensor) -> Tensor:
         return self.decoder(targets, self.encoder(x))
+
+    @torch.no_grad()
+    def generate(self, x: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True) -> Tensor:
+        """log-mel (B, n_mels, T) + prompt ids (B, P) -> greedy ids (B, P + max_new_tokens)."""
+        return self.decoder.generate(self.encoder(x), prompt, max_new_tokens, graph=graph)
 
     @staticmethod
     def from_openai(model_tag: str, *, pretrained: bool = False, **kwargs) -> "Whisper":
