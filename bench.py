@@ -170,14 +170,15 @@ def main():
     else:
         from bench_whisper import run_whisper
 
-        res = run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches)
+        res = run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, host_cores)
 
     if rank == 0:
         dt = res.pop("_dt")
         res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
         if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
-            res["cpu_baseline"] = cpu_baseline_vit() if args.workload == "vit" else res.get("cpu_baseline")
+            if args.workload == "vit":
+                res["cpu_baseline"] = cpu_baseline_vit()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

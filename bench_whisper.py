@@ -1,0 +1,114 @@
+"""Whisper leg of bench.py: log-mel + encoder + KV-cached greedy decode on 30 s synthetic clips."""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+PEAK_HBM_GBS = 8000.0
+N_NEW, PROMPT = 224, 4  # fixed prompt of 4 ids, max_seq_len // 2 new tokens
+
+
+def cpu_baseline_whisper(cores: int) -> dict:
+    """Oracle (kind "port") on the host: same pipeline, 2 clips, full 224-token KV-cached greedy decode."""
+    from oracle import ref_spectrogram as RS
+    from oracle import ref_whisper as RW
+    from pytorch_models.audio2text import Whisper
+    from synthweights import fill_module, synth_input, synth_tokens
+
+    torch.set_num_threads(cores)
+    m = Whisper.from_openai("base")
+    fill_module(m, 56)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    wave = synth_input("w_cpu", (2, 480000), 9, scale=0.1)
+    prompt = synth_tokens("w_cpu_p", (2, PROMPT), 51865, 9)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        mel = RS.whisper_log_mel(wave, 80, "rfft")
+        mem = RW.encoder(sd, "encoder.", mel)
+        RW.greedy_cached(sd, "decoder.", prompt, mem, N_NEW)
+        dt = time.perf_counter() - t0
+    return {"value": round(2 * 30 / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"2 x 30 s clips: log-mel + 8-layer encoder + {N_NEW}-token KV-cached greedy decode, fp32 oracle, "
+                      f"torch threads={cores} ({dt:.1f} s)"}
+
+
+def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, host_cores):
+    from pytorch_models._hip import ops
+    from pytorch_models.audio2text import Whisper, WhisperPreprocessor
+    from pytorch_models.audio2text.generate import GreedyDecoder
+    from synthweights import fill_module, synth_input, synth_tokens
+
+    B = args.batch or 32
+    tag = "base"
+    m = Whisper.from_openai(tag).eval()  # 8 layers, exactly as the reference builds "base" 
+    fill_module(m, 56)
+    m = m.to(torch.bfloat16).to(device)
+    pre = WhisperPreprocessor(tag).to(device)
+    wave = synth_input(f"w_bench_r{rank}", (B, 480000), 200 + rank, scale=0.1).to(device)
+    prompt = synth_tokens(f"w_bench_p{rank}", (B, PROMPT), 51865, 200 + rank).to(device)
+    gathered = [torch.empty(B, PROMPT + N_NEW, dtype=torch.int64, device=device) for _ in range(world)] if world > 1 else None
+
+    with torch.no_grad():
+        memory = m.encoder(pre(wave))
+        dec = GreedyDecoder(m.decoder, memory, prompt, N_NEW)
+        dec.run(graph=True)  # builds + captures the step graph once
+
+        def step():
+            mem = m.encoder(pre(wave))
+            dec.rebind(mem, prompt)
+            toks = dec.run(graph=True)
+            if world > 1:
+                dist.all_gather(gathered, toks)
+            return toks
+
+        for _ in range(args.warmup):
+            step()
+        sync(world)
+        ops.LAUNCH_LOG = {} if rank == 0 else None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync(world)
+        dt = time.perf_counter() - t0
+        log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    dt = max_over_ranks(dt, world, device)
+    res = {
+        "metric": "Whisper-base audio-sec/s (BASELINE.json: Whisper-base audio-sec/s & ViT-B/16 images/s)",
+        "value": round(world * B * 30.0 * args.steps / dt, 1),
+        "unit": "audio-s/s",
+        "config": {"workload": f"Whisper-base (reference geometry: 8 layers, d=512): log-mel + encoder + greedy decode "
+                               f"(prompt {PROMPT}, {N_NEW} new tokens, KV cache), 30 s synthetic audio, batch={B} per GPU "
+                               "(BASELINE configs[2])",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "collective": "all_gather(token ids)" if world > 1 else "none"},
+        "dtype": "bf16 weights and encoder activations, f32 decoder activations",
+        "_dt": dt,
+    }
+    if rank == 0:
+        kern = summarize_launches(log)
+        res["kernels"] = {k: {"launches": v["n"], "total_ms": round(v["ms"], 3)} for k, v in kern.items()}
+        # decode-step kernels run inside a graph during the timed region; time them in one extra EAGER pass with HIP
+        # events on the launch stream (same buffers, same data) for the roofline of the dominant decode kernel
+        with torch.no_grad():
+            dec.reset()
+            dlog = {}
+            for i in range(dec.n_steps):
+                dec.step(dlog if i % 8 == 0 else None)  # sample every 8th step: keeps the event count bounded
+            torch.cuda.synchronize()
+        S, d = memory.shape[1], memory.shape[2]
+        att = dlog["pm_dec_attention"]
+        cross = [(a, b) for a, b, ar in att if ar[6] is None]  # lk_ptr NULL <=> cross-attention
+        cross_ms = sum(a.elapsed_time(b) for a, b in cross)
+        cross_bytes = len(cross) * (2 * B * S * d * 2 + 2 * B * d * 4)
+        ach = cross_bytes / cross_ms / 1e6
+        res["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, 1500 keys)", "achieved": round(ach, 1),
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                           "launches": len(cross), "avg_launch_us": round(1e3 * cross_ms / len(cross), 2),
+                           "note": "timed in an extra eager pass after the timed region (the timed region replays a graph)"}
+        res["decode_kernels_eager_ms_per_step"] = {
+            k: round(sum(a.elapsed_time(b) for a, b, _ in v) / (len(v) / sum(1 for f, _ in dec.launches if f.__name__ == k)), 4)
+            for k, v in dlog.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_whisper(host_cores())
+    return res

@@ -120,7 +120,7 @@ int pm_dec_embed(const int64_t* tok_cur, const void* emb, const float* pos, cons
 /* y = act([LayerNorm_{gamma,beta,eps}](x) w^T + bias) [+ resid] for M <= 64 rows of f32 x; w bf16 (N, K).
  * gamma == NULL: no LayerNorm.  mode 0: out f32 (M, N) (+ resid f32, may alias out);
  * mode 1 (N = 3*inner, [q|k|v] blocks): q -> out f32 (M, inner); k, v -> bf16 caches (M, H, Tmax, 64) at position t;
- * mode 2: no store - per row, the tile's (max logit, lowest index) go to ws_val / ws_idx (M, ceil(N/16)).
+ * mode 2: no store - per row, the tile's (max logit, lowest index) go to ws_val / ws_idx (M, ceil(N/64)).
  * act: PM_ACT_NONE | PM_ACT_GELU (erff).  K % 32 == 0. */
 int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w,
                   int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M,

@@ -40,7 +40,7 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& hi, bf16x8& 
 
 enum { DL_PLAIN = 0, DL_QKV = 1, DL_ARGMAX = 2 };
 
-template <int ACT, int MT>
+template <int ACT, int MT, int FT>
 __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
                                                          const bf16* __restrict__ W, int64_t ldw,
@@ -49,11 +49,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
                                                          bf16* __restrict__ kcache, bf16* __restrict__ vcache, int inner,
                                                          int H, int Tmax, const int* __restrict__ pos_ptr,
                                                          float* __restrict__ ws_val, int* __restrict__ ws_idx, int nwg) {
+  // FT = 16-feature MFMA row tiles per workgroup (1 for the layer projections: more workgroups pull the weight
+  // stream; 4 for the 51865-row vocabulary: the x loads and the LayerNorm are amortised over 64 features)
   __shared__ float stats[64 * 2];
-  __shared__ __attribute__((aligned(16))) float red[4 * MT * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float red[4 * FT * MT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.x * DL_FEATS;
+  const int n0 = blockIdx.x * (DL_FEATS * FT);
   const bool ln = gamma != nullptr;
 
   if (ln) {  // per-row mean and rstd (two passes, like the reference's mean / biased variance): 8 threads per row
@@ -88,84 +90,122 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   }
 
   const int fi = lane & 15, kq = lane >> 4;
-  f32x4 acc[MT];
+  f32x4 acc[FT][MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int wrow = n0 + fi;
-  wrow = wrow < N ? wrow : N - 1;
-  const bf16* wp = W + (int64_t)wrow * ldw + kq * 8;
+  for (int f = 0; f < FT; ++f)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16* wp[FT];
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    int wrow = n0 + f * 16 + fi;
+    wrow = wrow < N ? wrow : N - 1;
+    wp[f] = W + (int64_t)wrow * ldw + kq * 8;
+  }
+  const float* xrow[MT];
+  float mean[MT], rstd[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int row = t * 16 + fi;
+    row = row < M ? row : M - 1;
+    xrow[t] = x + (int64_t)row * ldx + kq * 8;
+    mean[t] = ln ? stats[2 * row] : 0.f;
+    rstd[t] = ln ? stats[2 * row + 1] : 1.f;
+  }
   const int ksteps = K >> 5;
-  for (int s = wave; s < ksteps; s += 4) {
-    const int k0 = s * 32 + kq * 8;
-    const bf16x8 a = *(const bf16x8*)(wp + s * 32);
-    float g[8], bt[8];
-    if (ln) {
-      const f32x4 g0 = *(const f32x4*)(gamma + k0), g1 = *(const f32x4*)(gamma + k0 + 4);
-      const f32x4 b0 = *(const f32x4*)(beta + k0), b1 = *(const f32x4*)(beta + k0 + 4);
+  // The step is latency-bound: issue the loads of U k-steps (weights, activations, LayerNorm affine) back to back,
+  // then do their MFMAs - one memory round trip per block of U instead of one per k-step.
+  constexpr int U = FT == 1 ? 4 : 2;
+  for (int sb = wave; sb < ksteps; sb += 4 * U) {
+    bf16x8 a[U][FT];
+    f32x4 xv[U][MT][2], gv[U][2], bv[U][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { g[i] = g0[i]; g[4 + i] = g1[i]; bt[i] = b0[i]; bt[4 + i] = b1[i]; }
+    for (int u = 0; u < U; ++u) {
+      int s = sb + 4 * u;
+      s = s < ksteps ? s : ksteps - 1;
+#pragma unroll
+      for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        xv[u][t][0] = *(const f32x4*)(xrow[t] + s * 32);
+        xv[u][t][1] = *(const f32x4*)(xrow[t] + s * 32 + 4);
+      }
+      if (ln) {
+        const int k0 = s * 32 + kq * 8;
+        gv[u][0] = *(const f32x4*)(gamma + k0);
+        gv[u][1] = *(const f32x4*)(gamma + k0 + 4);
+        bv[u][0] = *(const f32x4*)(beta + k0);
+        bv[u][1] = *(const f32x4*)(beta + k0 + 4);
+      }
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      int row = t * 16 + fi;
-      row = row < M ? row : M - 1;
-      const float* xr = x + (int64_t)row * ldx + k0;
-      const f32x4 v0 = *(const f32x4*)xr, v1 = *(const f32x4*)(xr + 4);
-      float v[8];
+    for (int u = 0; u < U; ++u) {
+      if (sb + 4 * u >= ksteps) break;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = v0[i]; v[4 + i] = v1[i]; }
-      if (ln) {
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+      for (int t = 0; t < MT; ++t) {
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean) * rstd * g[i] + bt[i];
+        for (int i = 0; i < 4; ++i) { v[i] = xv[u][t][0][i]; v[4 + i] = xv[u][t][1][i]; }
+        if (ln) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gv[u][i >> 2][i & 3] + bv[u][i >> 2][i & 3];
+        }
+        bf16x8 hi, mid, lo;
+        split3(v, hi, mid, lo);
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], hi, acc[f][t], 0, 0, 0);
+          acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], mid, acc[f][t], 0, 0, 0);
+          acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], lo, acc[f][t], 0, 0, 0);
+        }
       }
-      bf16x8 hi, mid, lo;
-      split3(v, hi, mid, lo);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, hi, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, mid, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, lo, acc[t], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int t = 0; t < MT; ++t) *(f32x4*)(red + ((wave * MT + t) * 64 + lane) * 4) = acc[t];
+  for (int f = 0; f < FT; ++f)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(f32x4*)(red + (((wave * FT + f) * MT + t) * 64 + lane) * 4) = acc[f][t];
   __syncthreads();
   if (wave != 0) return;
 
   // D[row = feature 4*kq + r][col = sequence fi]; partial sums added in wave order 0..3
-  const int n = n0 + kq * 4;
   const int tpos = (mode == DL_QKV) ? *pos_ptr : 0;
   float best_v[MT];
   int best_i[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    f32x4 v = *(const f32x4*)(red + ((0 * MT + t) * 64 + lane) * 4);
+  for (int t = 0; t < MT; ++t) { best_v[t] = -INFINITY; best_i[t] = 0x7fffffff; }
 #pragma unroll
-    for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + ((w * MT + t) * 64 + lane) * 4);
-    const int row = t * 16 + fi;
-    best_v[t] = -INFINITY;
-    best_i[t] = 0x7fffffff;
+  for (int f = 0; f < FT; ++f) {
+    const int n = n0 + f * 16 + kq * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int nn = n + r;
-      if (nn >= N) continue;
-      float e = v[r] + (bias ? bias[nn] : 0.f);
-      e = apply_act<ACT, true>(e);
-      if (mode == DL_ARGMAX) {
-        if (e > best_v[t]) { best_v[t] = e; best_i[t] = nn; }  // ascending nn: strict > keeps the lowest index
-        continue;
-      }
-      if (row >= M) continue;
-      if (mode == DL_PLAIN) {
-        if (resid) e += resid[(int64_t)row * ldr + nn];
-        out[(int64_t)row * ldo + nn] = e;
-      } else {  // DL_QKV: [q | k | v] column blocks of width inner
-        const int which = nn / inner, c = nn - which * inner;
-        if (which == 0) {
-          out[(int64_t)row * ldo + c] = e;
-        } else {
-          bf16* cache = which == 1 ? kcache : vcache;
-          const int h = c >> 6, dd = c & 63;
-          cache[(((int64_t)row * H + h) * Tmax + tpos) * 64 + dd] = (bf16)e;
+    for (int t = 0; t < MT; ++t) {
+      f32x4 v = *(const f32x4*)(red + (((0 * FT + f) * MT + t) * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + (((w * FT + f) * MT + t) * 64 + lane) * 4);
+      const int row = t * 16 + fi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n + r;
+        if (nn >= N) continue;
+        float e = v[r] + (bias ? bias[nn] : 0.f);
+        e = apply_act<ACT, true>(e);
+        if (mode == DL_ARGMAX) {
+          if (e > best_v[t]) { best_v[t] = e; best_i[t] = nn; }  // ascending nn: strict > keeps the lowest index
+          continue;
+        }
+        if (row >= M) continue;
+        if (mode == DL_PLAIN) {
+          if (resid) e += resid[(int64_t)row * ldr + nn];
+          out[(int64_t)row * ldo + nn] = e;
+        } else {  // DL_QKV: [q | k | v] column blocks of width inner
+          const int which = nn / inner, c = nn - which * inner;
+          if (which == 0) {
+            out[(int64_t)row * ldo + c] = e;
+          } else {
+            bf16* cache = which == 1 ? kcache : vcache;
+            const int h = c >> 6, dd = c & 63;
+            cache[(((int64_t)row * H + h) * Tmax + tpos) * 64 + dd] = (bf16)e;
+          }
         }
       }
     }
@@ -371,13 +411,13 @@ extern "C" int pm_dec_embed(const int64_t* tok_cur, const void* emb, const float
   return PM_OK;
 }
 
-template <int ACT>
+template <int ACT, int FT>
 static void dl_launch(int mt, dim3 grid, hipStream_t st, const float* x, int ldx, const float* gamma, const float* beta,
                       float eps, const bf16* W, int64_t ldw, const float* bias, const float* resid, int ldr, float* out,
                       int ldo, int M, int N, int K, int mode, bf16* kc, bf16* vc, int inner, int H, int Tmax,
                       const int* pos_ptr, float* wv, int* wi, int nwg) {
 #define PM_DL(T)                                                                                                      \
-  hipLaunchKernelGGL((dec_linear_kernel<ACT, T>), grid, dim3(256), 0, st, x, ldx, gamma, beta, eps, W, ldw, bias, resid, \
+  hipLaunchKernelGGL((dec_linear_kernel<ACT, T, FT>), grid, dim3(256), 0, st, x, ldx, gamma, beta, eps, W, ldw, bias, resid, \
                      ldr, out, ldo, M, N, K, mode, kc, vc, inner, H, Tmax, pos_ptr, wv, wi, nwg)
   if (mt == 1) PM_DL(1);
   else if (mt == 2) PM_DL(2);
@@ -408,15 +448,20 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
     return PM_EINVAL;
   }
   if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
-  const int nwg = (int)((N + DL_FEATS - 1) / DL_FEATS);
+  const int ft = mode == DL_ARGMAX ? 4 : 1;
+  const int nwg = (int)((N + DL_FEATS * ft - 1) / (DL_FEATS * ft));
   const int mt = (int)((M + 15) / 16);
   hipStream_t st = (hipStream_t)stream;
-  if (act == PM_ACT_GELU)
-    dl_launch<PM_ACT_GELU>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+  if (mode == DL_ARGMAX)
+    dl_launch<PM_ACT_NONE, 4>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+                              (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
+                              (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
+  else if (act == PM_ACT_GELU)
+    dl_launch<PM_ACT_GELU, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                            (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   else
-    dl_launch<PM_ACT_NONE>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+    dl_launch<PM_ACT_NONE, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                            (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   PM_CHECK_LAUNCH();

@@ -60,7 +60,7 @@ class GreedyDecoder:
         self.tokens = torch.zeros(B, self.Ttot, dtype=torch.int64, device=dev)
         self.tokens[:, :P] = self.prompt
         self.margins = torch.zeros(B, self.Ttot, **f32) if margins else None
-        n_tiles = (V + 15) // 16
+        n_tiles = (V + 63) // 64  # pm_dec_linear mode 2 reduces 64-feature tiles
         self.ws_val = torch.empty(B, n_tiles, **f32)
         self.ws_idx = torch.empty(B, n_tiles, dtype=torch.int32, device=dev)
         pos_f32 = _f32(dec, "pos", dec.pos_embs)
@@ -81,7 +81,7 @@ class GreedyDecoder:
 
         add(L.pm_dec_embed, self.tok_cur.data_ptr(), E.data_ptr(), pos_f32.data_ptr(), self.pos.data_ptr(), self.x.data_ptr(),
             B, d, V, None)
-        self.self_k, self.self_v, self.cross_kv = [], [], []
+        self.self_k, self.self_v, self.cross_kv, self._cross_w = [], [], [], []
         for layer in dec.layers:
             if not layer.pre_norm or layer.ca is None:
                 raise NotImplementedError("greedy decode: pre-norm layers with cross-attention only")
@@ -102,6 +102,7 @@ class GreedyDecoder:
             wkv, bkv = ca._pack("kv")
             kv = ops.linear(mem2, wkv, bkv)
             self.cross_kv.append(kv)
+            self._cross_w.append((wkv, bkv))
             g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
             dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, _f32(ca.q_proj, "b", ca.q_proj.bias), None, self.q,
                        inner)
@@ -123,10 +124,28 @@ class GreedyDecoder:
             self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot, _ptr(self.margins), B, None)
         add(L.pm_dec_advance, self.pos.data_ptr(), None)
 
-    def step(self) -> None:
+    def rebind(self, memory: Tensor, prompt: Tensor) -> None:
+        """New clips, same geometry: re-project the cross K/V INTO the existing buffers and swap the prompt, so the
+        captured graph (which holds raw pointers) stays valid."""
+        B, S, d = memory.shape
+        assert (B, self.P) == tuple(prompt.shape) and B == self.B and memory.dtype == torch.bfloat16
+        mem2 = memory.reshape(B * S, d)
+        for kv, (wkv, bkv) in zip(self.cross_kv, self._cross_w):
+            assert kv.shape[0] == B * S
+            ops.linear(mem2, wkv, bkv, out=kv)
+        self.prompt.copy_(prompt)
+        self.tokens[:, : self.P] = self.prompt
+
+    def step(self, log: dict | None = None) -> None:
         st = torch.cuda.current_stream().cuda_stream
         for fn, args in self.launches:
+            if log is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             rc = fn(*args[:-1], st)
+            if log is not None:
+                e1.record()
+                log.setdefault(fn.__name__, []).append((e0, e1, args))
             if rc:
                 check(rc, fn.__name__)
 
