@@ -156,13 +156,225 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large-M variant: PERSISTENT, 256 (tokens) x 128 (features) x 64 tile, 8 waves as 4 x 2 (each wave still 64 x 64),
+// one workgroup per CU, 3-stage LDS ring (3 x 48 KiB = 144 KiB).
+//  * The K steps of all tiles a workgroup owns form ONE stream; two steps are always in flight: the wait for step p
+//    is a COUNTED s_waitcnt vmcnt(6) (6 = LDS-DMA instructions per wave per step) followed by a raw s_barrier, so the
+//    loads of step p+1 stay in flight across the barrier and step p+2 is issued right behind it
+//    (cdna_hip_programming.md, "Pipelining across barriers").
+//  * Because the stream runs across tile boundaries, the first two K steps of the NEXT tile are already in flight while
+//    the current tile's epilogue runs: at K = 768 (12 steps per tile) the per-tile prologue / epilogue bubble was ~40 %
+//    of the tile time in the one-tile-per-workgroup form.
+//  * Epilogue: bias / activation in the accumulator layout, then each wave transposes its 64 x 64 result IN FP32 through
+//    4 KiB of the ring buffer the last step just freed (16 tokens at a time); the residual is read and the result is
+//    stored row-wise - 128-byte segments, 16 bytes per lane - and rounded to bf16 exactly once.
+//  * XCD locality: the 32 workgroups that share an XCD (blockIdx % 8: a label, speed only) walk one contiguous
+//    eighth of the tile list together, so they share token panels and the weight panel in that XCD's L2.
+constexpr int LBM = 256, LBN = 128;
+constexpr int STAGE_BYTES = (LBM + LBN) * BK * 2;  // 48 KiB
+constexpr int PERSIST_WGS = 256;
+
+template <int ACT, bool YF32>
+__global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+    const void* resid, int64_t ldr, int resid_f32, int resid_period, void* Y, int64_t ldy, int M, int N, int K,
+    int tiles_n, int ntiles, int x_rows_per_batch, int64_t x_batch_stride, int vec_ok) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // this workgroup's tiles: chunk of XCD group (blockIdx % 8), strided by the 32 workgroups of the group
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+  const int cq = ntiles >> 3, cr = ntiles & 7;
+  const int tbase = xcd * cq + (xcd < cr ? xcd : cr), tcount = cq + (xcd < cr ? 1 : 0);
+  const int my_tiles = local < tcount ? (tcount - local + nloc - 1) / nloc : 0;
+  const int nk = K / BK;
+  const int P = my_tiles * nk;  // K steps in this workgroup's stream
+
+  // staging side of the stream.  Written as a macro over plain locals (not a capturing lambda): with mutable
+  // by-reference captures hipcc can keep such state in scratch memory, whose loads/stores are VMEM ops that drain
+  // the counted-vmcnt pipeline every step (measured: 4x slower).
+  int64_t xoff[4], woff[2];
+  int pp = 0, pp_kt = 0, pp_tile = 0, pp_buf = 0;
+#define PM_STAGE_NEXT()                                                                                              \
+  if (pp < P) {                                                                                                      \
+    if (pp_kt == 0) {                                                                                                \
+      const int t_ = tbase + local + pp_tile * nloc;                                                                 \
+      const int tm_ = t_ / tiles_n, tn_ = t_ - tm_ * tiles_n;                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+        const int rt = wave * 32 + i * 8 + (lane >> 3);                                                              \
+        int gm = tm_ * LBM + rt;                                                                                     \
+        gm = gm < M ? gm : M - 1;                                                                                    \
+        const int chunk = swz_pos(rt, lane & 7);                                                                     \
+        if (x_rows_per_batch > 0) {                                                                                  \
+          const int bb = gm / x_rows_per_batch;                                                                      \
+          xoff[i] = (int64_t)bb * x_batch_stride + (int64_t)(gm - bb * x_rows_per_batch) * ldx + chunk * 8;          \
+        } else {                                                                                                     \
+          xoff[i] = (int64_t)gm * ldx + chunk * 8;                                                                   \
+        }                                                                                                            \
+      }                                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+        const int rt = wave * 16 + i * 8 + (lane >> 3);                                                              \
+        int gn = tn_ * LBN + rt;                                                                                     \
+        gn = gn < N ? gn : N - 1;                                                                                    \
+        woff[i] = (int64_t)gn * ldw + swz_pos(rt, lane & 7) * 8;                                                     \
+      }                                                                                                              \
+    }                                                                                                                \
+    char* xs_ = smem + pp_buf * STAGE_BYTES;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(X + xoff[i] + pp_kt * BK, xs_ + (wave * 32 + i * 8) * 128); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+        glds16(W + woff[i] + pp_kt * BK, xs_ + LBM * 128 + (wave * 16 + i * 8) * 128);                                \
+    ++pp;                                                                                                            \
+    pp_buf = pp_buf == 2 ? 0 : pp_buf + 1;                                                                           \
+    if (++pp_kt == nk) { pp_kt = 0; ++pp_tile; }                                                                     \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  PM_STAGE_NEXT();
+  PM_STAGE_NEXT();
+  const int fr = lane & 15, fq = lane >> 4;
+  int buf = 0, kt = 0, ti = 0;
+  for (int pc = 0; pc < P; ++pc) {
+    // step pc landed; step pc+1 may stay in flight.  (Exact bookkeeping that also lets the epilogue's stores stay in
+    // flight across tile boundaries was measured: no gain, +VGPRs - the epilogue is VALU/LDS-bound, not drain-bound.)
+    if (pp - pc >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's part landed; every wave is past step pc-1: its buffer is free
+    PM_STAGE_NEXT();
+    const char* xcur = smem + buf * STAGE_BYTES;
+    const char* wcur = xcur + LBM * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = read_frag(wcur, wn * 64 + j * 16 + fr, s * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = read_frag(xcur, wm * 64 + i * 16 + fr, s * 4 + fq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
+    }
+    const int cbuf = buf;
+    buf = buf == 2 ? 0 : buf + 1;
+    if (++kt < nk) continue;
+
+    // ---------------- tile finished: epilogue (the next tile's first two K steps are already in flight)
+    kt = 0;
+#ifdef PM_ABLATE_EPILOGUE  // experiment only: keep the accumulators live, skip the epilogue
+    {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[j][i])); acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      ++ti;
+      continue;
+    }
+#endif
+    const int t = tbase + local + ti * nloc;
+    ++ti;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int m0 = tm * LBM + wm * 64, n0 = tn * LBN + wn * 64;
+    if (vec_ok && !YF32 && !(resid && resid_f32)) {
+      // fp32 staging through the ring buffer this step just consumed (free once every wave is past its MFMAs;
+      // it is not re-filled before the barrier at the top of the next step): 4 KiB per wave.
+      __builtin_amdgcn_s_barrier();
+      char* stg = smem + cbuf * STAGE_BYTES + wave * 4096;
+      const int srow = lane >> 3, sch = lane & 7;  // row-wise side: 8 lanes x 8 features per 64-feature row segment
+      // residual first (coalesced 16-byte loads in the STORE layout), so its latency hides under the staging
+      bf16x8 rv[4][2];
+      if (resid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            int mm = m0 + i * 16 + srow + p * 8;
+            mm = mm < M ? mm : M - 1;
+            int nn = n0 + sch * 8;
+            nn = nn < N ? nn : N - 8;
+            rv[i][p] = *(const bf16x8*)((const bf16*)resid + (int64_t)(resid_period ? mm % resid_period : mm) * ldr + nn);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + j * 16 + fq * 4;
+          f32x4 v = acc[j][i];
+          acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (bias && n < N) v += *(const f32x4*)(bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT, false>(v[r]);
+          // staging row fr (64 f32 = 256 B), 16-byte chunk c = 4j + fq stored at position c ^ fr
+          *(f32x4*)(stg + fr * 256 + (((4 * j + fq) ^ fr) * 16)) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int row = srow + p * 8;
+          const f32x4 lo = *(const f32x4*)(stg + row * 256 + (((2 * sch) ^ row) * 16));
+          const f32x4 hi = *(const f32x4*)(stg + row * 256 + (((2 * sch + 1) ^ row) * 16));
+          bf16x8 o;
+          if (resid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = (bf16)(lo[r] + (float)rv[i][p][r]); o[4 + r] = (bf16)(hi[r] + (float)rv[i][p][4 + r]); }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = (bf16)lo[r]; o[4 + r] = (bf16)hi[r]; }
+          }
+          const int mm = m0 + i * 16 + row, nn = n0 + sch * 8;
+#ifdef PM_ABLATE_STORES  // experiment only
+          asm volatile("" ::"v"(o));
+#else
+          if (mm < M && nn < N) *(bf16x8*)((bf16*)Y + (int64_t)mm * ldy + nn) = o;  // N % 8 == 0 on this path
+#endif
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j * 16 + fq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + i * 16 + fr;
+          f32x4 v = acc[j][i];
+          acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (n >= N || m >= M) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (n + r >= N) continue;
+            float e = v[r] + (bias ? bias[n + r] : 0.f);
+            e = apply_act<ACT, YF32>(e);
+            if (resid) {
+              const int64_t ro = (int64_t)(resid_period ? m % resid_period : m) * ldr + n + r;
+              e += resid_f32 ? ((const float*)resid)[ro] : (float)((const bf16*)resid)[ro];
+            }
+            if constexpr (YF32) ((float*)Y)[(int64_t)m * ldy + n + r] = e;
+            else ((bf16*)Y)[(int64_t)m * ldy + n + r] = (bf16)e;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <bool YF32>
-int launch_act(int act, dim3 grid, hipStream_t st, const bf16* X, int64_t ldx, const bf16* W, int64_t ldw,
+int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int64_t ldx, const bf16* W, int64_t ldw,
                const float* bias, const void* resid, int64_t ldr, int resid_f32, int resid_period, void* Y, int64_t ldy,
                int M, int N, int K, int tiles_n, int xrpb, int64_t xbs, int vec_ok) {
-#define PM_GO(A)                                                                                                    \
-  hipLaunchKernelGGL((linear_bf16_kernel<A, YF32>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, resid, ldr, resid_f32, \
-                     resid_period, Y, ldy, M, N, K, tiles_n, xrpb, xbs, vec_ok);                                    \
+#define PM_GO(A)                                                                                                       \
+  if (big)                                                                                                             \
+    hipLaunchKernelGGL((linear_bf16_persist_kernel<A, YF32>), dim3(PERSIST_WGS), dim3(512), 0, st, X, ldx, W, ldw, bias, \
+                       resid, ldr, resid_f32, resid_period, Y, ldy, M, N, K, tiles_n, (int)grid.x, xrpb, xbs, vec_ok); \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((linear_bf16_kernel<A, YF32>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, resid, ldr,          \
+                       resid_f32, resid_period, Y, ldy, M, N, K, tiles_n, xrpb, xbs, vec_ok);                          \
   break
   switch (act) {
     case PM_ACT_NONE: PM_GO(PM_ACT_NONE);
@@ -194,16 +406,19 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
                      !((uintptr_t)y & (y_dtype == PM_F32 ? 15 : 7)) && !(bias && ((uintptr_t)bias & 15)) &&
                      !(resid && ((uintptr_t)resid & (resid_dtype == PM_F32 ? 15 : 7)));
   if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || resid_period > (1 << 30)) return PM_EINVAL;
-  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  // 256 x 128 tiles (deep LDS ring, one workgroup per CU) once there are enough of them to fill the chip a few times
+  const bool big = (M >= 4096) && ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512 &&
+                   (y_dtype == PM_F32 || !vec_ok || (N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15)));
+  const int tiles_m = (int)((M + (big ? LBM : BM) - 1) / (big ? LBM : BM)), tiles_n = (int)((N + BN - 1) / BN);
   const int64_t nblk = (int64_t)tiles_m * tiles_n;
   if (nblk > 0x7fffffff) return PM_EINVAL;
   dim3 grid((unsigned)nblk);
   hipStream_t st = (hipStream_t)stream;
   int rc = (y_dtype == PM_F32)
-               ? launch_act<true>(act, grid, st, (const bf16*)x, ldx, (const bf16*)w, ldw, bias, resid, ldr,
+               ? launch_act<true>(act, big, grid, st, (const bf16*)x, ldx, (const bf16*)w, ldw, bias, resid, ldr,
                                   resid_dtype == PM_F32, (int)resid_period, y, ldy, (int)M, (int)N, (int)K, tiles_n,
                                   (int)x_rows_per_batch, x_batch_stride, vec_ok)
-               : launch_act<false>(act, grid, st, (const bf16*)x, ldx, (const bf16*)w, ldw, bias, resid, ldr,
+               : launch_act<false>(act, big, grid, st, (const bf16*)x, ldx, (const bf16*)w, ldw, bias, resid, ldr,
                                    resid_dtype == PM_F32, (int)resid_period, y, ldy, (int)M, (int)N, (int)K, tiles_n,
                                    (int)x_rows_per_batch, x_batch_stride, vec_ok);
   if (rc != PM_OK) return rc;

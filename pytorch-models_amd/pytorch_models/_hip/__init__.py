@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))  # .../pytorch-models_amd
-LIB_PATH = os.path.join(REPO_PKG_ROOT, "csrc", "build", "libpm_mi355x.so")
+LIB_PATH = os.environ.get("PM_MI355X_LIB") or os.path.join(REPO_PKG_ROOT, "csrc", "build", "libpm_mi355x.so")
 HEADER_PATH = os.path.join(os.path.dirname(REPO_PKG_ROOT), "include", "pm_mi355x.h")
 
 PM_BF16, PM_F32 = 0, 1

@@ -37,7 +37,8 @@ def ops():
 
 
 # ---------------------------------------------------------------- linear
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 768, 768), (1, 64, 64), (333, 2304, 768), (50, 192, 3072), (257, 132, 128)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 768, 768), (1, 64, 64), (333, 2304, 768), (50, 192, 3072), (257, 132, 128),
+                                   (40000, 388, 64), (33000, 1024, 192)])  # the last two take the 256x128 ring kernel
 @pytest.mark.parametrize("act", ["none", "gelu"])
 def test_linear_shapes(ops, M, N, K, act):
     x = bf(synth_input("lin_x", (M, K), 1))
