@@ -97,12 +97,13 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
                 dec.step(dlog if i % 8 == 0 else None)  # sample every 8th step: keeps the event count bounded
             torch.cuda.synchronize()
         S, d = memory.shape[1], memory.shape[2]
-        att = dlog["pm_dec_attention"]
-        cross = [(a, b) for a, b, ar in att if ar[6] is None]  # lk_ptr NULL <=> cross-attention
+        att = dlog["pm_dec_attention_fused"]
+        cross = [(a, b) for a, b, ar in att if ar[18] == 0]  # self_attn == 0 <=> cross-attention block
         cross_ms = sum(a.elapsed_time(b) for a, b in cross)
-        cross_bytes = len(cross) * (2 * B * S * d * 2 + 2 * B * d * 4)
+        # algorithmic bytes per launch: packed cross K/V (bf16) + x, out (f32) + the q projection weight once
+        cross_bytes = len(cross) * (2 * B * S * d * 2 + 2 * B * d * 4 + d * d * 2)
         ach = cross_bytes / cross_ms / 1e6
-        res["roofline"] = {"bound": "hbm", "kernel": "dec_attn_kernel (cross-attention, 1500 keys)", "achieved": round(ach, 1),
+        res["roofline"] = {"bound": "hbm", "kernel": "dec_attn_fused_kernel<false> (LN + q-proj + cross-attention over 1500 keys)", "achieved": round(ach, 1),
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                            "launches": len(cross), "avg_launch_us": round(1e3 * cross_ms / len(cross), 2),
                            "note": "timed in an extra eager pass after the timed region (the timed region replays a graph)"}

@@ -120,18 +120,33 @@ int pm_dec_embed(const int64_t* tok_cur, const void* emb, const float* pos, cons
 /* y = act([LayerNorm_{gamma,beta,eps}](x) w^T + bias) [+ resid] for M <= 64 rows of f32 x; w bf16 (N, K).
  * gamma == NULL: no LayerNorm.  mode 0: out f32 (M, N) (+ resid f32, may alias out);
  * mode 1 (N = 3*inner, [q|k|v] blocks): q -> out f32 (M, inner); k, v -> bf16 caches (M, H, Tmax, 64) at position t;
- * mode 2: no store - per row, the tile's (max logit, lowest index) go to ws_val / ws_idx (M, ceil(N/64)).
+ * mode 2: no store - per row, the tile's (max logit, lowest index) go to ws_val / ws_idx (M, ceil(N / tile)),
+ *         tile = pm_dec_argmax_tile(K) features.  With LayerNorm: K <= 1280.
  * act: PM_ACT_NONE | PM_ACT_GELU (erff).  K % 32 == 0. */
 int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w,
                   int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M,
                   int64_t N, int64_t K, int act, int mode, void* kcache, void* vcache, int64_t inner, int64_t H,
                   int64_t Tmax, const int32_t* pos_ptr, float* ws_val, int32_t* ws_idx, void* stream);
 
+/* Features per argmax tile of pm_dec_linear mode 2 for a given K (64, or 32 when K > 512). */
+int pm_dec_argmax_tile(int64_t K);
+
 /* One query per (sequence, head), head_dim 64: out = softmax(q K^T / 8) V (transformer.py:52 with L_q = 1 and NO
  * causal flag - SURVEY.md F3).  q / out f32 (B, H*64); K/V bf16 addressed base + b*stride_b + h*stride_h + key*stride_k;
  * number of keys = (lk_ptr ? *lk_ptr : 0) + lk_add  (self: pos + 1; cross: the constant 1500), <= lk_max <= 4096. */
 int pm_dec_attention(const float* q, const void* kc, const void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
                      const int32_t* lk_ptr, int64_t lk_add, int64_t lk_max, float* out, int64_t B, int64_t H, void* stream);
+
+/* Fused attention block of the decode step, one launch: LayerNorm(x[b]) -> per-head projection -> attention.
+ * self_attn != 0: w = packed [q|k|v] bf16 (3*H*64, d), bias f32 (3*H*64) or NULL; k_h, v_h are rounded to bf16,
+ *   appended to the caches kc / vc at position t = *pos_ptr and attended together with the t older keys;
+ * self_attn == 0: w = q projection bf16 (H*64, d); kc / vc = the projected cross K / V, lk_const keys.
+ * K/V addressing and q/out layout as pm_dec_attention.  d % 64 == 0, d <= 1280.  Replaces pm_dec_linear (mode 0/1)
+ * + pm_dec_attention for the same result (same fp32 arithmetic, k/v rounding point unchanged). */
+int pm_dec_attention_fused(const float* x, int64_t d, const float* gamma, const float* beta, float eps, const void* w,
+                           const float* bias, void* kc, void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
+                           const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, float* out, int64_t B, int64_t H,
+                           int self_attn, void* stream);
 
 /* Finish the argmax over the n_tiles tile winners of pm_dec_linear mode 2 (lowest index on ties, like torch.argmax),
  * teacher-force the prompt (next = prompt[b, t+1] while t + 1 < P), write tok_cur[b] and tokens_out[b, t+1]. */

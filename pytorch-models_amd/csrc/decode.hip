@@ -40,7 +40,12 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& hi, bf16x8& 
 
 enum { DL_PLAIN = 0, DL_QKV = 1, DL_ARGMAX = 2 };
 
-template <int ACT, int MT, int FT>
+// NSTEP = K steps of 32 per wave held in registers at once.  LayerNorm kernels (K = d_model) keep the wave's WHOLE
+// share of x in registers: the row statistics come from those registers (two exchanges through LDS: mean, then the
+// centred second moment - the reference's two-pass form), so x is read from memory exactly once and every load of the
+// kernel (x, weights) is issued before the first wait: one memory round trip.  The earlier form re-read x for the
+// statistics in a scalar loop whose loads each paid a full L2 round trip (~15 us per launch, all latency).
+template <int ACT, int MT, int FT, int NSTEP, bool LN>
 __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
                                                          const bf16* __restrict__ W, int64_t ldw,
@@ -49,47 +54,15 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
                                                          bf16* __restrict__ kcache, bf16* __restrict__ vcache, int inner,
                                                          int H, int Tmax, const int* __restrict__ pos_ptr,
                                                          float* __restrict__ ws_val, int* __restrict__ ws_idx, int nwg) {
-  // FT = 16-feature MFMA row tiles per workgroup (1 for the layer projections: more workgroups pull the weight
-  // stream; 4 for the 51865-row vocabulary: the x loads and the LayerNorm are amortised over 64 features)
-  __shared__ float stats[64 * 2];
+  __shared__ float part[4 * 64];
+  __shared__ float gb[LN ? 2 * 1280 : 2];
   __shared__ __attribute__((aligned(16))) float red[4 * FT * MT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * (DL_FEATS * FT);
-  const bool ln = gamma != nullptr;
-
-  if (ln) {  // per-row mean and rstd (two passes, like the reference's mean / biased variance): 8 threads per row
-    for (int r0 = 0; r0 < M; r0 += 32) {
-      const int row = r0 + (tid >> 3), part = tid & 7;
-      const int rr = row < M ? row : M - 1;
-      const float* xr = x + (int64_t)rr * ldx;
-      float s = 0.f;
-      for (int k = part * 4; k < K; k += 32) {
-        const f32x4 v = *(const f32x4*)(xr + k);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-      }
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      const float mean = s / (float)K;
-      float q = 0.f;
-      for (int k = part * 4; k < K; k += 32) {
-        const f32x4 v = *(const f32x4*)(xr + k);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q = fmaf(v[i] - mean, v[i] - mean, q);
-      }
-      q += __shfl_xor(q, 1, 64);
-      q += __shfl_xor(q, 2, 64);
-      q += __shfl_xor(q, 4, 64);
-      if (part == 0 && row < M) {
-        stats[2 * row] = mean;
-        stats[2 * row + 1] = rsqrtf(q / (float)K + eps);
-      }
-    }
-    __syncthreads();
-  }
-
   const int fi = lane & 15, kq = lane >> 4;
+  const int ksteps = K >> 5;
+
   f32x4 acc[FT][MT];
 #pragma unroll
   for (int f = 0; f < FT; ++f)
@@ -103,52 +76,90 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
     wp[f] = W + (int64_t)wrow * ldw + kq * 8;
   }
   const float* xrow[MT];
-  float mean[MT], rstd[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     int row = t * 16 + fi;
     row = row < M ? row : M - 1;
     xrow[t] = x + (int64_t)row * ldx + kq * 8;
-    mean[t] = ln ? stats[2 * row] : 0.f;
-    rstd[t] = ln ? stats[2 * row + 1] : 1.f;
   }
-  const int ksteps = K >> 5;
-  // The step is latency-bound: issue the loads of U k-steps (weights, activations, LayerNorm affine) back to back,
-  // then do their MFMAs - one memory round trip per block of U instead of one per k-step.
-  constexpr int U = FT == 1 ? 4 : 2;
-  for (int sb = wave; sb < ksteps; sb += 4 * U) {
-    bf16x8 a[U][FT];
-    f32x4 xv[U][MT][2], gv[U][2], bv[U][2];
+
+  // LN kernels: exactly ONE trip for every wave (host guarantees ksteps <= 4*NSTEP), even a wave that owns no K step:
+  // the trip contains workgroup barriers
+  for (int sb = wave, trip = 0; LN ? trip < 1 : sb < ksteps; sb += 4 * NSTEP, ++trip) {
+    bf16x8 a[NSTEP][FT];
+    f32x4 xv[NSTEP][MT][2];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < NSTEP; ++u) {
       int s = sb + 4 * u;
       s = s < ksteps ? s : ksteps - 1;
-#pragma unroll
-      for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         xv[u][t][0] = *(const f32x4*)(xrow[t] + s * 32);
         xv[u][t][1] = *(const f32x4*)(xrow[t] + s * 32 + 4);
       }
-      if (ln) {
-        const int k0 = s * 32 + kq * 8;
-        gv[u][0] = *(const f32x4*)(gamma + k0);
-        gv[u][1] = *(const f32x4*)(gamma + k0 + 4);
-        bv[u][0] = *(const f32x4*)(beta + k0);
-        bv[u][1] = *(const f32x4*)(beta + k0 + 4);
+#pragma unroll
+      for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
+    }
+    float mean[MT], rstd[MT];
+    if constexpr (LN) {
+      for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[1280 + k] = beta[k]; }
+      // ---- mean: lane partial over its elements, then over the 4 kq lanes, then over the 4 waves through LDS
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < NSTEP; ++u)
+          if (sb + 4 * u < ksteps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm += xv[u][t][0][i] + xv[u][t][1][i];
+          }
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if (kq == 0) part[wave * 64 + t * 16 + fi] = sm;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int r = t * 16 + fi;
+        mean[t] = ((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < NSTEP; ++u)
+          if (sb + 4 * u < ksteps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float d0 = xv[u][t][0][i] - mean[t], d1 = xv[u][t][1][i] - mean[t];
+              q = fmaf(d0, d0, q);
+              q = fmaf(d1, d1, q);
+            }
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (kq == 0) part[wave * 64 + t * 16 + fi] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int r = t * 16 + fi;
+        rstd[t] = rsqrtf(((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K + eps);
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < NSTEP; ++u) {
       if (sb + 4 * u >= ksteps) break;
+      const int k0 = (sb + 4 * u) * 32 + kq * 8;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = xv[u][t][0][i]; v[4 + i] = xv[u][t][1][i]; }
-        if (ln) {
+        if constexpr (LN) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gv[u][i >> 2][i & 3] + bv[u][i >> 2][i & 3];
+          for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gb[k0 + i] + gb[1280 + k0 + i];
         }
         bf16x8 hi, mid, lo;
         split3(v, hi, mid, lo);
@@ -353,6 +364,236 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Fused attention block of the decode step: one 512-thread workgroup per (sequence b, head h) does
+//   LayerNorm(x[b]) -> q_h (cross) or q_h, k_h, v_h (self; k_h, v_h rounded to bf16 and appended to the cache at t)
+//   -> softmax(q_h K_h^T / 8) V_h over the cache (self: t + 1 keys, the new one taken from LDS) or over the packed
+//   cross K/V (1500 keys) -> att[b, h*64 : h*64 + 64].
+// This replaces the [LN + projection] dec_linear launch in front of each attention (2 of 8 launches per layer): the
+// projection for one (b, h) is a 64 x d (or 192 x d) GEMV whose weights sit in L2, shared by the 32 sequences.
+// The K/V stream is what bounds the cross block (HBM): 8 waves x 8 x 16 B per lane = 64 KiB in flight per CU.
+#ifndef PM_CROSS_NKU
+#define PM_CROSS_NKU 4
+#endif
+constexpr int DF_THREADS = 512, DF_WAVES = 8;
+
+__device__ __forceinline__ float block_reduce8(float v, float* scratch, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float r = scratch[0];
+#pragma unroll
+  for (int w = 1; w < DF_WAVES; ++w) r = is_max ? fmaxf(r, scratch[w]) : r + scratch[w];
+  return r;
+}
+
+template <bool SELF, int NCH>
+__global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
+    const float* __restrict__ x, int d, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const bf16* __restrict__ Wp, const float* __restrict__ bp,  // SELF: packed [q|k|v] (3*inner, d); cross: q (inner, d)
+    bf16* Kc, bf16* Vc, int64_t sb, int64_t sh, int64_t sk, const int* __restrict__ pos_ptr, int lk_const,
+    float* __restrict__ out, int H) {
+  __shared__ float sc[DA_MAXK];
+  __shared__ float xn[1280];
+  __shared__ float qkv[192];
+  __shared__ float scratch[DF_WAVES];
+  __shared__ float part[DF_WAVES * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int inner = H * 64;
+  const int tpos = SELF ? *pos_ptr : 0;
+  const int Lk = SELF ? tpos + 1 : lk_const;
+  const int nproj = SELF ? 3 : 1;
+
+  // ---- the K stream does not depend on q: request its first NKU passes (cross block: all 1500 keys = 192 KiB) before
+  // anything else, so HBM streams while the LayerNorm and the projection run.  8 lanes per key, 64 keys per pass.
+  constexpr int NKU = SELF ? 4 : PM_CROSS_NKU;
+  const int c = lane & 7, ks = lane >> 3;
+  const bf16* kb = Kc + b * sb + h * sh + c * 8;
+  const bf16* vb = Vc + b * sb + h * sh + c * 8;
+  const int Lc = SELF ? Lk - 1 : Lk;  // keys read from memory (self: the newest one comes from LDS)
+  bf16x8 kv[NKU];
+#pragma unroll
+  for (int u = 0; u < NKU; ++u) {
+    int key = u * 64 + wave * 8 + ks;
+    key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
+    kv[u] = *(const bf16x8*)(kb + key * sk);
+  }
+  // ---- projection weights: 8 lanes per output row, lane p owns 16-byte chunks p, p+8, ...
+  const int prow = tid >> 3, pl = tid & 7;
+  const int nch = d >> 6;  // chunks per lane (d % 64 == 0)
+  // NCH = compile-time bound on nch; all projections' weights are requested up front unless that would not fit the
+  // register file (self block at d_model 1280: one projection at a time)
+  constexpr bool UPFRONT = !(SELF && NCH > 16);
+  bf16x8 wv[UPFRONT ? (SELF ? 3 : 1) : 1][NCH];
+  if constexpr (UPFRONT) {
+#pragma unroll
+    for (int o = 0; o < (SELF ? 3 : 1); ++o) {
+      const bf16* wr = Wp + ((int64_t)o * inner + h * 64 + prow) * d + pl * 8;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (i < nch) wv[o][i] = *(const bf16x8*)(wr + i * 64);
+    }
+  }
+  // ---- LayerNorm of row b (two-pass from registers)
+  const float* xr = x + (int64_t)b * d;
+  float xe[3];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int k = tid + i * DF_THREADS;
+    xe[i] = k < d ? xr[k] : 0.f;
+    s += xe[i];
+  }
+  const float mean = block_reduce8(s, scratch, false) / (float)d;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int k = tid + i * DF_THREADS;
+    if (k < d) q2 = fmaf(xe[i] - mean, xe[i] - mean, q2);
+  }
+  const float rstd = rsqrtf(block_reduce8(q2, scratch, false) / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int k = tid + i * DF_THREADS;
+    if (k < d) xn[k] = (xe[i] - mean) * rstd * gamma[k] + beta[k];
+  }
+  __syncthreads();
+  // ---- q (k, v) = W xn + b : fp32 FMA over this lane's chunks, then across the 8 lanes of the row
+#pragma unroll
+  for (int o = 0; o < (SELF ? 3 : 1); ++o) {
+    float acc = 0.f;
+    if constexpr (!UPFRONT) {
+      const bf16* wr = Wp + ((int64_t)o * inner + h * 64 + prow) * d + pl * 8;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (i < nch) wv[0][i] = *(const bf16x8*)(wr + i * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (i < nch) {
+        const float* xp = xn + i * 64 + pl * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[UPFRONT ? o : 0][i][e], xp[e], acc);
+      }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (pl == 0) {
+      float v = acc + (bp ? bp[o * inner + h * 64 + prow] : 0.f);
+      if (SELF && o > 0) {  // cached k / v are bf16: round once, store, and use the rounded value for this step too
+        const bf16 r = (bf16)v;
+        (o == 1 ? Kc : Vc)[b * sb + h * sh + (int64_t)tpos * sk + prow] = r;
+        v = (float)r;
+      }
+      qkv[o * 64 + prow] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- scores
+  const f32x4 q0 = *(const f32x4*)(qkv + c * 8), q1 = *(const f32x4*)(qkv + c * 8 + 4);
+  for (int k0 = 0; k0 < Lc; k0 += 64 * NKU) {
+    if (k0 > 0) {
+#pragma unroll
+      for (int u = 0; u < NKU; ++u) {
+        int key = k0 + u * 64 + wave * 8 + ks;
+        key = key < Lc ? key : Lc - 1;
+        kv[u] = *(const bf16x8*)(kb + key * sk);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NKU; ++u) {
+      float sv = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], (float)kv[u][i], sv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], (float)kv[u][4 + i], sv);
+      sv += __shfl_xor(sv, 1, 64);
+      sv += __shfl_xor(sv, 2, 64);
+      sv += __shfl_xor(sv, 4, 64);
+      const int key = k0 + u * 64 + wave * 8 + ks;
+      if (c == 0 && key < Lc) sc[key] = sv * 0.125f;
+    }
+  }
+  if (SELF && tid < 8) {  // the new key (position t), same summation shape as above
+    float sv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], qkv[64 + c * 8 + i], sv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], qkv[64 + c * 8 + 4 + i], sv);
+    sv += __shfl_xor(sv, 1, 64);
+    sv += __shfl_xor(sv, 2, 64);
+    sv += __shfl_xor(sv, 4, 64);
+    if (c == 0) sc[Lk - 1] = sv * 0.125f;
+  }
+  // V does not depend on the scores: request the first NKU passes now, so they fly during the softmax reductions
+  bf16x8 vv[NKU];
+#pragma unroll
+  for (int u = 0; u < NKU; ++u) {
+    int key = u * 64 + wave * 8 + ks;
+    key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
+    vv[u] = *(const bf16x8*)(vb + key * sk);
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int k = tid; k < Lk; k += DF_THREADS) mx = fmaxf(mx, sc[k]);
+  mx = block_reduce8(mx, scratch, true);
+  float sum = 0.f;
+  for (int k = tid; k < Lk; k += DF_THREADS) {
+    const float p = expf(sc[k] - mx);
+    sc[k] = p;
+    sum += p;
+  }
+  sum = block_reduce8(sum, scratch, false);  // its barriers also publish the p values
+
+  // ---- P.V
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < Lc; k0 += 64 * NKU) {
+    if (k0 > 0) {
+#pragma unroll
+      for (int u = 0; u < NKU; ++u) {
+        int key = k0 + u * 64 + wave * 8 + ks;
+        key = key < Lc ? key : Lc - 1;
+        vv[u] = *(const bf16x8*)(vb + key * sk);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NKU; ++u) {
+      const int key = k0 + u * 64 + wave * 8 + ks;
+      const float p = key < Lc ? sc[key] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[u][i], acc[i]);
+    }
+  }
+  if (SELF && wave == 0 && ks == 0) {
+    const float p = sc[Lk - 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, qkv[128 + c * 8 + i], acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] += __shfl_xor(acc[i], 8, 64);
+    acc[i] += __shfl_xor(acc[i], 16, 64);
+    acc[i] += __shfl_xor(acc[i], 32, 64);
+  }
+  if (ks == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[wave * 64 + c * 8 + i] = acc[i];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float o = 0.f;
+#pragma unroll
+    for (int w = 0; w < DF_WAVES; ++w) o += part[w * 64 + tid];
+    out[((int64_t)b * H + h) * 64 + tid] = o / sum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __restrict__ ws_val, const int* __restrict__ ws_idx,
                                                                 int nwg, const int* __restrict__ pos_ptr,
                                                                 const int64_t* __restrict__ prompt, int P,
@@ -411,20 +652,38 @@ extern "C" int pm_dec_embed(const int64_t* tok_cur, const void* emb, const float
   return PM_OK;
 }
 
-template <int ACT, int FT>
-static void dl_launch(int mt, dim3 grid, hipStream_t st, const float* x, int ldx, const float* gamma, const float* beta,
-                      float eps, const bf16* W, int64_t ldw, const float* bias, const float* resid, int ldr, float* out,
-                      int ldo, int M, int N, int K, int mode, bf16* kc, bf16* vc, int inner, int H, int Tmax,
-                      const int* pos_ptr, float* wv, int* wi, int nwg) {
-#define PM_DL(T)                                                                                                      \
-  hipLaunchKernelGGL((dec_linear_kernel<ACT, T, FT>), grid, dim3(256), 0, st, x, ldx, gamma, beta, eps, W, ldw, bias, resid, \
-                     ldr, out, ldo, M, N, K, mode, kc, vc, inner, H, Tmax, pos_ptr, wv, wi, nwg)
-  if (mt == 1) PM_DL(1);
-  else if (mt == 2) PM_DL(2);
-  else if (mt == 3) PM_DL(3);
-  else PM_DL(4);
-#undef PM_DL
+#define PM_DL_ARGS                                                                                                   \
+  x, ldx, gamma, beta, eps, W, ldw, bias, resid, ldr, out, ldo, M, N, K, mode, kc, vc, inner, H, Tmax, pos_ptr, wv, wi, nwg
+template <int ACT, int FT, int NSTEP, bool LN>
+static void dl_launch_mt(int mt, dim3 grid, hipStream_t st, const float* x, int ldx, const float* gamma, const float* beta,
+                         float eps, const bf16* W, int64_t ldw, const float* bias, const float* resid, int ldr, float* out,
+                         int ldo, int M, int N, int K, int mode, bf16* kc, bf16* vc, int inner, int H, int Tmax,
+                         const int* pos_ptr, float* wv, int* wi, int nwg) {
+  if (mt <= 1) hipLaunchKernelGGL((dec_linear_kernel<ACT, 1, FT, NSTEP, LN>), grid, dim3(256), 0, st, PM_DL_ARGS);
+  else if (mt == 2) hipLaunchKernelGGL((dec_linear_kernel<ACT, 2, FT, NSTEP, LN>), grid, dim3(256), 0, st, PM_DL_ARGS);
+  else hipLaunchKernelGGL((dec_linear_kernel<ACT, 4, FT, NSTEP, LN>), grid, dim3(256), 0, st, PM_DL_ARGS);
 }
+
+template <int ACT, int FT>
+static int dl_launch(int mt, dim3 grid, hipStream_t st, const float* x, int ldx, const float* gamma, const float* beta,
+                     float eps, const bf16* W, int64_t ldw, const float* bias, const float* resid, int ldr, float* out,
+                     int ldo, int M, int N, int K, int mode, bf16* kc, bf16* vc, int inner, int H, int Tmax,
+                     const int* pos_ptr, float* wv, int* wi, int nwg) {
+  const int per_wave = (K / 32 + 3) / 4;  // K steps each wave owns
+  if (gamma) {  // LayerNorm: the wave's whole share of x must sit in registers
+    if (mt > 2 && per_wave > 4) return PM_EUNSUPPORTED;
+    if (per_wave <= 4) dl_launch_mt<ACT, FT, 4, true>(mt, grid, st, PM_DL_ARGS);
+    else if (per_wave <= 8 && FT == 1) dl_launch_mt<ACT, FT, 8, true>(mt, grid, st, PM_DL_ARGS);
+    else if (per_wave <= 10 && FT == 1) dl_launch_mt<ACT, FT, 10, true>(mt, grid, st, PM_DL_ARGS);
+    else if (per_wave <= 10) dl_launch_mt<ACT, FT == 1 ? 1 : 2, 10, true>(mt, grid, st, PM_DL_ARGS);
+    else return PM_EUNSUPPORTED;
+  } else {
+    if (per_wave <= 4 || mt > 2) dl_launch_mt<ACT, FT, 4, false>(mt, grid, st, PM_DL_ARGS);
+    else dl_launch_mt<ACT, FT, 8, false>(mt, grid, st, PM_DL_ARGS);
+  }
+  return PM_OK;
+}
+#undef PM_DL_ARGS
 
 extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w,
                              int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo,
@@ -448,25 +707,36 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
     return PM_EINVAL;
   }
   if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
-  const int ft = mode == DL_ARGMAX ? 4 : 1;
+  if (K > 1280 && gamma) return PM_EUNSUPPORTED;
+  const int per_wave = (int)((K / 32 + 3) / 4);
+  const int ft = mode == DL_ARGMAX ? (gamma && per_wave > 4 ? 2 : 4) : 1;  // see pm_dec_argmax_tile()
   const int nwg = (int)((N + DL_FEATS * ft - 1) / (DL_FEATS * ft));
   const int mt = (int)((M + 15) / 16);
   hipStream_t st = (hipStream_t)stream;
-  if (mode == DL_ARGMAX)
-    dl_launch<PM_ACT_NONE, 4>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+  int rc = PM_OK;
+  if (mode == DL_ARGMAX && ft == 2)
+    rc = dl_launch<PM_ACT_NONE, 2>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+                              (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
+                              (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
+  else if (mode == DL_ARGMAX)
+    rc = dl_launch<PM_ACT_NONE, 4>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                               (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                               (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   else if (act == PM_ACT_GELU)
-    dl_launch<PM_ACT_GELU, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+    rc = dl_launch<PM_ACT_GELU, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                            (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   else
-    dl_launch<PM_ACT_NONE, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+    rc = dl_launch<PM_ACT_NONE, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                            (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
+  if (rc != PM_OK) return rc;
   PM_CHECK_LAUNCH();
   return PM_OK;
 }
+
+/* features per argmax tile for a given K (callers size ws_val / ws_idx as ceil(N / tile)) */
+extern "C" int pm_dec_argmax_tile(int64_t K) { return ((K / 32 + 3) / 4 > 4) ? 32 : 64; }
 
 extern "C" int pm_dec_attention(const float* q, const void* kc, const void* vc, int64_t stride_b, int64_t stride_h,
                                 int64_t stride_k, const int32_t* lk_ptr, int64_t lk_add, int64_t lk_max, float* out,
@@ -479,6 +749,38 @@ extern "C" int pm_dec_attention(const float* q, const void* kc, const void* vc, 
   if (B * H > 0x7fffffff) return PM_EINVAL;
   hipLaunchKernelGGL(dec_attn_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, q, (const bf16*)kc,
                      (const bf16*)vc, stride_b, stride_h, stride_k, (const int*)lk_ptr, (int)lk_add, out, (int)H);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+extern "C" int pm_dec_attention_fused(const float* x, int64_t d, const float* gamma, const float* beta, float eps,
+                                      const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
+                                      int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
+                                      int64_t lk_max, float* out, int64_t B, int64_t H, int self_attn, void* stream) {
+  if (!x || !gamma || !beta || !w || !kc || !vc || !out || B <= 0 || H <= 0 || d <= 0 || lk_max <= 0) return PM_EINVAL;
+  if (d % 64 || d > 1280 || lk_max > DA_MAXK) return PM_EUNSUPPORTED;
+  if (self_attn ? !pos_ptr : lk_const <= 0) return PM_EINVAL;
+  if ((stride_b | stride_h | stride_k) % 8) return PM_EALIGN;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)out) & 15) return PM_EALIGN;
+  if (B * H > 0x7fffffff) return PM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (int)(d / 64);
+#define PM_DF(SELF_, NCH_)                                                                                            \
+  hipLaunchKernelGGL((dec_attn_fused_kernel<SELF_, NCH_>), dim3((unsigned)(B * H)), dim3(DF_THREADS), 0, st, x, (int)d,   \
+                     gamma, beta, eps, (const bf16*)w, bias, (bf16*)kc, (bf16*)vc, stride_b, stride_h, stride_k,          \
+                     (const int*)pos_ptr, (int)lk_const, out, (int)H)
+  if (self_attn) {
+    if (nch <= 8) PM_DF(true, 8);
+    else if (nch <= 12) PM_DF(true, 12);
+    else if (nch <= 16) PM_DF(true, 16);
+    else PM_DF(true, 20);
+  } else {
+    if (nch <= 8) PM_DF(false, 8);
+    else if (nch <= 12) PM_DF(false, 12);
+    else if (nch <= 16) PM_DF(false, 16);
+    else PM_DF(false, 20);
+  }
+#undef PM_DF
   PM_CHECK_LAUNCH();
   return PM_OK;
 }

@@ -31,7 +31,9 @@ SIGNATURES = {
     "pm_embed_tokens": ([_p, _p, _p, _p, _i, _l, _l, _l, _l, _l, _p], c_int),
     "pm_dec_embed": ([_p, _p, _p, _p, _p, _l, _l, _l, _p], c_int),
     "pm_dec_linear": ([_p, _l, _p, _p, _f, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _p, _p, _l, _l, _l, _p, _p, _p, _p], c_int),
+    "pm_dec_argmax_tile": ([_l], c_int),
     "pm_dec_attention": ([_p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _p], c_int),
+    "pm_dec_attention_fused": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p], c_int),
     "pm_dec_argmax_reduce": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _l, _p], c_int),
     "pm_dec_advance": ([_p, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),

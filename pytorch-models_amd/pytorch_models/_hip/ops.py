@@ -269,7 +269,8 @@ def dec_argmax(x: Tensor, w: Tensor, ln: tuple) -> tuple[Tensor, Tensor]:
     """Per-row argmax (and max) of LN(x) @ w.T without materialising the logits."""
     M, K = x.shape
     N = w.shape[0]
-    nt = (N + 63) // 64
+    tile = lib().pm_dec_argmax_tile(K)
+    nt = (N + tile - 1) // tile
     wv = torch.empty(M, nt, dtype=torch.float32, device=x.device)
     wi = torch.empty(M, nt, dtype=torch.int32, device=x.device)
     g, b, eps = ln

@@ -24,7 +24,7 @@ def _ptr(t: Tensor | None):
 class GreedyDecoder:
     """State + launch list of the decode step for one (decoder, batch, memory length) geometry."""
 
-    def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False) -> None:
+    def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False, fused: bool = True) -> None:
         E = dec.token_embs.weight
         if E.dtype != torch.bfloat16 or not E.is_cuda:
             raise NotImplementedError("greedy decode: bf16 weights on a HIP device only (model.to(torch.bfloat16).cuda())")
@@ -60,12 +60,13 @@ class GreedyDecoder:
         self.tokens = torch.zeros(B, self.Ttot, dtype=torch.int64, device=dev)
         self.tokens[:, :P] = self.prompt
         self.margins = torch.zeros(B, self.Ttot, **f32) if margins else None
-        n_tiles = (V + 63) // 64  # pm_dec_linear mode 2 reduces 64-feature tiles
+        L = lib()
+        tile = L.pm_dec_argmax_tile(d)
+        n_tiles = (V + tile - 1) // tile  # pm_dec_linear mode 2 leaves one (max, index) per tile and sequence
         self.ws_val = torch.empty(B, n_tiles, **f32)
         self.ws_idx = torch.empty(B, n_tiles, dtype=torch.int32, device=dev)
         pos_f32 = _f32(dec, "pos", dec.pos_embs)
         mem2 = memory.reshape(B * S, d)
-        L = lib()
         self._keep = [E, pos_f32, memory]  # tensors the launch list points into
         self.launches = []  # (fn, args): raw pointers only -> the loop has no per-step Python work beyond ctypes
 
@@ -92,9 +93,15 @@ class GreedyDecoder:
             self.self_v.append(vc)
             wqkv, bqkv = sa._pack("qkv")
             g, b = _f32(layer.sa_norm, "g", layer.sa_norm.weight), _f32(layer.sa_norm, "b", layer.sa_norm.bias)
-            dec_linear(self.x, d, g, b, layer.sa_norm.eps, wqkv, bqkv, None, self.q, 3 * inner, mode=1, kc=kc, vc=vc)
-            add(L.pm_dec_attention, self.q.data_ptr(), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64,
-                self.pos.data_ptr(), 1, Tmax, self.att.data_ptr(), B, H, None)
+            self._keep += [wqkv, bqkv, g, b]
+            if fused:  # LN + q/k/v projection + cache append + attention in one launch per layer
+                add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
+                    wqkv.data_ptr(), _ptr(bqkv), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64, self.pos.data_ptr(),
+                    0, Tmax, self.att.data_ptr(), B, H, 1, None)
+            else:
+                dec_linear(self.x, d, g, b, layer.sa_norm.eps, wqkv, bqkv, None, self.q, 3 * inner, mode=1, kc=kc, vc=vc)
+                add(L.pm_dec_attention, self.q.data_ptr(), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64,
+                    self.pos.data_ptr(), 1, Tmax, self.att.data_ptr(), B, H, None)
             dec_linear(self.att, inner, None, None, 0.0, sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), self.x,
                        self.x, d)
             # cross attention: K/V of the memory projected ONCE (the reference re-projects them on every call,
@@ -104,10 +111,16 @@ class GreedyDecoder:
             self.cross_kv.append(kv)
             self._cross_w.append((wkv, bkv))
             g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
-            dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, _f32(ca.q_proj, "b", ca.q_proj.bias), None, self.q,
-                       inner)
-            add(L.pm_dec_attention, self.q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64, 2 * inner,
-                None, S, S, self.att.data_ptr(), B, H, None)
+            bq = _f32(ca.q_proj, "b", ca.q_proj.bias)
+            self._keep += [g, b, bq]
+            if fused:
+                add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
+                    ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
+                    2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
+            else:
+                dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, bq, None, self.q, inner)
+                add(L.pm_dec_attention, self.q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
+                    2 * inner, None, S, S, self.att.data_ptr(), B, H, None)
             dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), self.x,
                        self.x, d)
             g, b = _f32(layer.mlp_norm, "g", layer.mlp_norm.weight), _f32(layer.mlp_norm, "b", layer.mlp_norm.bias)
@@ -174,8 +187,10 @@ class GreedyDecoder:
 
 
 @torch.no_grad()
-def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: bool = True, margins: bool = False):
-    """tokens (B, P + n_new) int64 [and per-position diagnostic margins]."""
-    st = GreedyDecoder(dec, memory, prompt, n_new, margins)
+def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: bool = True, margins: bool = False,
+                  fused: bool = True):
+    """tokens (B, P + n_new) int64 [and per-position diagnostic margins].  fused=False uses the unfused
+    projection + attention launches (same arithmetic, 2 more launches per layer)."""
+    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused)
     toks = st.run(graph)
     return (toks, st.margins) if margins else toks

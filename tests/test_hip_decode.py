@@ -34,7 +34,7 @@ def ops():
     return o
 
 
-@pytest.mark.parametrize("M,N,K", [(32, 512, 512), (2, 1536, 384), (33, 64, 2048), (64, 100, 64), (1, 16, 32)])
+@pytest.mark.parametrize("M,N,K", [(32, 512, 512), (2, 1536, 384), (33, 64, 2048), (64, 100, 64), (1, 16, 32), (32, 640, 1280), (17, 96, 768)])
 def test_dec_linear_fp32_exact(ops, M, N, K):
     x = synth_input("dl_x", (M, K), 1) * 2
     w = bf(synth_input("dl_w", (N, K), 2, scale=K ** -0.5))
@@ -45,6 +45,8 @@ def test_dec_linear_fp32_exact(ops, M, N, K):
     torch.testing.assert_close(got.cpu().double(), want, rtol=2e-6, atol=2e-6)
     got = ops.dec_linear(x.cuda(), w.cuda(), b.cuda(), act="gelu", resid=r.cuda())
     torch.testing.assert_close(got.cpu(), (RT.activation(want, "gelu") + r.double()).float(), rtol=1e-5, atol=1e-5)
+    if K > 1280 or (M > 32 and K > 512):
+        return  # fused LayerNorm keeps a wave's share of x in registers: d_model <= 1280 (<= 512 beyond 32 rows)
     g, be = synth_input("dl_g", (K,), 5, scale=0.1) + 1, synth_input("dl_be", (K,), 6, scale=0.1)
     xn = RT.layernorm({"weight": g.double(), "bias": be.double()}, "", x.double(), 1e-5)
     got = ops.dec_linear(x.cuda(), w.cuda(), None, ln=(g.cuda(), be.cuda(), 1e-5))
@@ -122,6 +124,10 @@ def test_greedy_ids_bit_exact_vs_oracle(tag, seed):
     assert _compare(toks, want, margins, 4) == 0
     # eager launches and graph replay are the same program
     assert torch.equal(w.decoder.generate(memory, prompt.cuda(), n_new, graph=False), toks)
+    # the unfused launch list (separate projection and attention kernels) decodes the same ids
+    from pytorch_models.audio2text.generate import greedy_decode
+
+    assert torch.equal(greedy_decode(w.decoder, memory, prompt.cuda(), n_new, fused=False), toks)
 
 
 def test_greedy_end_to_end_agrees_with_reference_golden(golden):
