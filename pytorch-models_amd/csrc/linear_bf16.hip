@@ -256,6 +256,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
   PM_STAGE_NEXT();
   PM_STAGE_NEXT();
   const int fr = lane & 15, fq = lane >> 4;
+  const bool staged_epi = vec_ok && !YF32 && !(resid && resid_f32);
+  bf16x8 rv[4][2];
   int buf = 0, kt = 0, ti = 0;
   for (int pc = 0; pc < P; ++pc) {
     // step pc landed; step pc+1 may stay in flight.  (Exact bookkeeping that also lets the epilogue's stores stay in
@@ -264,6 +266,23 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part landed; every wave is past step pc-1: its buffer is free
     PM_STAGE_NEXT();
+    if (kt == nk - 1 && staged_epi && resid) {
+      // last K step of the tile: request the residual now (coalesced 16-byte loads in the STORE layout) so that its
+      // latency hides under this step's 32 MFMAs instead of stalling the epilogue
+      int tm_r, tn_r;
+      tile_coords(tbase + local + ti * nloc, tiles_m, tiles_n, tm_r, tn_r);
+      const int m0r = tm_r * LBM + wm * 64, n0r = tn_r * LBN + wn * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          int mm = m0r + i * 16 + (lane >> 3) + p * 8;
+          mm = mm < M ? mm : M - 1;
+          int nn = n0r + (lane & 7) * 8;
+          nn = nn < N ? nn : N - 8;
+          rv[i][p] = *(const bf16x8*)((const bf16*)resid + (int64_t)(resid_period ? mm % resid_period : mm) * ldr + nn);
+        }
+    }
     const char* xcur = smem + buf * STAGE_BYTES;
     const char* wcur = xcur + LBM * 128;
     {
@@ -307,34 +326,24 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * LBM + wm * 64, n0 = tn * LBN + wn * 64;
-    if (vec_ok && !YF32 && !(resid && resid_f32)) {
+    if (staged_epi) {
       // fp32 staging through the ring buffer this step just consumed (free once every wave is past its MFMAs;
       // it is not re-filled before the barrier at the top of the next step): 4 KiB per wave.
       __builtin_amdgcn_s_barrier();
       char* stg = smem + cbuf * STAGE_BYTES + wave * 4096;
       const int srow = lane >> 3, sch = lane & 7;  // row-wise side: 8 lanes x 8 features per 64-feature row segment
-      // residual first (coalesced 16-byte loads in the STORE layout), so its latency hides under the staging
-      bf16x8 rv[4][2];
-      if (resid) {
+      f32x4 bvec[4];  // this lane's bias values, loaded once per tile (not per 16-token chunk)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            int mm = m0 + i * 16 + srow + p * 8;
-            mm = mm < M ? mm : M - 1;
-            int nn = n0 + sch * 8;
-            nn = nn < N ? nn : N - 8;
-            rv[i][p] = *(const bf16x8*)((const bf16*)resid + (int64_t)(resid_period ? mm % resid_period : mm) * ldr + nn);
-          }
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j * 16 + fq * 4;
+        bvec[j] = (bias && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int n = n0 + j * 16 + fq * 4;
-          f32x4 v = acc[j][i];
+          f32x4 v = acc[j][i] + bvec[j];
           acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (bias && n < N) v += *(const f32x4*)(bias + n);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT, false>(v[r]);
           // staging row fr (64 f32 = 256 B), 16-byte chunk c = 4j + fq stored at position c ^ fr

@@ -160,3 +160,27 @@ def test_greedy_batch32_full_length_properties():
     small = w.decoder.generate(memory2, prompt2.cuda(), 224)
     assert torch.equal(toks[:2], small) and torch.equal(toks[2:4], small)
     assert torch.equal(w.decoder.generate(memory, prompt.cuda(), 224), toks)
+
+
+def test_whisper_large_v2_geometry_config4():
+    """BASELINE config[3] geometry (Whisper large-v2: 32 layers, d = 1280, 20 heads) on one GPU at a batch the
+    oracle can follow: log-mel + encoder within the bf16 tolerance, greedy ids bit-exact given the same memory."""
+    from pytorch_models.audio2text import Whisper, WhisperPreprocessor
+
+    w = Whisper.from_openai("large-v2").eval()
+    fill_module(w, 57)
+    bf16_round_(w)
+    sd = {k: v.clone() for k, v in w.state_dict().items()}
+    w = w.to(torch.bfloat16).cuda()
+    wave = synth_input("w_wave_large", (1, 480000), 57, scale=0.1)
+    mel = WhisperPreprocessor("large-v2").cuda()(wave.cuda())
+    memory = w.encoder(mel)
+    assert memory.shape == (1, 1500, 1280)
+    want_mem = RW.encoder(sd, "encoder.", RS.whisper_log_mel(wave, 80, "rfft"))
+    rel = ((memory.float().cpu() - want_mem).norm() / want_mem.norm()).item()
+    print(f"large-v2 encoder rel-L2 vs oracle: {rel:.3e}")
+    assert rel < 3e-2  # 32 bf16 layers
+    prompt = synth_tokens("w_prompt_large", (1, 4), 51865, 57)
+    toks = w.decoder.generate(memory, prompt.cuda(), 8)
+    want, margins = RW.greedy_cached(sd, "decoder.", prompt, memory.float().cpu(), 8, rp=kv_round)
+    assert _compare(toks, want, margins, 4) == 0
