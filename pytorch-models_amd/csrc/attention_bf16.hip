@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
   // tr-read lane geometry (see header): 16-lane group g, lane-in-group i = 4*qq + pp
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
 
+  const bool wave_live = q0 + wave * 32 < Lq;
   load_tile(0);
   write_tile(smem);
   __syncthreads();
@@ -101,12 +102,19 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
     const char* vbuf = kbuf + TILE_B;
     if (t + 1 < nT) load_tile(t + 1);
 
+    // work that cannot contribute is skipped per wave (the K/V staging and the barrier are not): a wave whose 32
+    // queries are all past Lq, a causal tile entirely above the wave's last query, and the second 32-key block of a
+    // tail tile when it holds no valid key (L = 197: 5 of the last tile's 64 keys exist)
+    const bool kb1 = t * KV_TILE + 32 < Lk;
+    const bool skip = !wave_live || (CAUSAL && t * KV_TILE > q0 + wave * 32 + 31);
+    if (!skip) {
     // ---- S^T = K Q^T : two 32-key blocks
     f32x16 sc[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) sc[kb][i] = kb == 1 && !kb1 ? -1e30f : 0.f;
+      if (kb == 1 && !kb1) continue;  // second 32-key block holds no valid key (tail tile): skip its MFMAs
       const int row = kb * 32 + r;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+        if (kb == 1 && !kb1) continue;
         float v = sc[kb][i] * c;
         if (tail || diag) {
           const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+        if (kb == 1 && !kb1) continue;
         const float p = __builtin_amdgcn_exp2f(sc[kb][i] - m_new);
         sc[kb][i] = p;
         ps += p;
@@ -154,6 +164,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (kb == 1 && !kb1) continue;
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (bf16)sc[kb][8 * s + j];
@@ -168,6 +179,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
         }
       }
 
+    }
     if (t + 1 < nT) write_tile(smem + ((t + 1) & 1) * 2 * TILE_B);
     __syncthreads();
   }
