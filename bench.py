@@ -39,6 +39,15 @@ def host_cores() -> int:
     return min(n, 64)
 
 
+def measured_traffic(name: str):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/collect_traffic.py;
+    PMC cannot be sampled from inside this process).  None if no measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", name)
+    if not os.path.exists(path):
+        return None
+    return round(json.load(open(path))["traffic_bytes_per_launch"])
+
+
 def vit_flops_per_image(n_layers=12, d=768, L=197, patches=196, k_patch=768) -> float:
     """n_layers * (24 L d^2 + 4 L^2 d) + 2 * patches * K * d."""
     return n_layers * (24 * L * d * d + 4 * L * L * d) + 2 * patches * k_patch * d
@@ -115,7 +124,8 @@ def run_vit(args, rank, world, device):
         lin = kern["linear_bf16"]
         ach = lin["work"] / lin["ms"] / 1e9  # flop / ms -> TFLOP/s
         res["roofline"] = {"bound": "mfma", "kernel": "linear_bf16_kernel", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                           "traffic": measured_traffic("vit_traffic.json"), "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01/vit_traffic.json)",
                            "launches": lin["n"], "avg_launch_us": round(1e3 * lin["ms"] / lin["n"], 2)}
         res["kernels"] = {k: {"launches": v["n"], "total_ms": round(v["ms"], 3)} for k, v in kern.items()}
         res["model_tflops"] = round(vit_flops_per_image() * B * args.steps / dt / 1e12, 1)
