@@ -368,6 +368,8 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 //   LayerNorm(x[b]) -> q_h (cross) or q_h, k_h, v_h (self; k_h, v_h rounded to bf16 and appended to the cache at t)
 //   -> softmax(q_h K_h^T / 8) V_h over the cache (self: t + 1 keys, the new one taken from LDS) or over the packed
 //   cross K/V (1500 keys) -> att[b, h*64 : h*64 + 64].
+// The cross K/V is read once per step by exactly one CU: it is loaded NON-TEMPORALLY so that the 0.8 GB per step of
+// streamed K/V does not evict the decoder's weights (120 MB + 53 MB of embeddings) from the 256 MiB Infinity Cache.
 // This replaces the [LN + projection] dec_linear launch in front of each attention (2 of 8 launches per layer): the
 // projection for one (b, h) is a 64 x d (or 192 x d) GEMV whose weights sit in L2, shared by the 32 sequences.
 // The K/V stream is what bounds the cross block (HBM): 8 waves x 8 x 16 B per lane = 64 KiB in flight per CU.
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   for (int u = 0; u < NKU; ++u) {
     int key = u * 64 + wave * 8 + ks;
     key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-    kv[u] = *(const bf16x8*)(kb + key * sk);
+    kv[u] = SELF ? *(const bf16x8*)(kb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(kb + key * sk));
   }
   // ---- projection weights: 8 lanes per output row, lane p owns 16-byte chunks p, p+8, ...
   const int prow = tid >> 3, pl = tid & 7;
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       for (int u = 0; u < NKU; ++u) {
         int key = k0 + u * 64 + wave * 8 + ks;
         key = key < Lc ? key : Lc - 1;
-        kv[u] = *(const bf16x8*)(kb + key * sk);
+        kv[u] = SELF ? *(const bf16x8*)(kb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(kb + key * sk));
       }
     }
 #pragma unroll
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   for (int u = 0; u < NKU; ++u) {
     int key = u * 64 + wave * 8 + ks;
     key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-    vv[u] = *(const bf16x8*)(vb + key * sk);
+    vv[u] = SELF ? *(const bf16x8*)(vb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(vb + key * sk));
   }
   __syncthreads();
   float mx = -INFINITY;
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       for (int u = 0; u < NKU; ++u) {
         int key = k0 + u * 64 + wave * 8 + ks;
         key = key < Lc ? key : Lc - 1;
-        vv[u] = *(const bf16x8*)(vb + key * sk);
+        vv[u] = SELF ? *(const bf16x8*)(vb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(vb + key * sk));
       }
     }
 #pragma unroll
