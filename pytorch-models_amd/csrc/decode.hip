@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
                                                          int H, int Tmax, const int* __restrict__ pos_ptr,
                                                          float* __restrict__ ws_val, int* __restrict__ ws_idx, int nwg) {
   __shared__ float part[4 * 64];
-  __shared__ float gb[LN ? 2 * 1280 : 2];
+  constexpr int GBK = 128 * NSTEP;  // the largest K this instantiation serves (host: ksteps <= 4 * NSTEP)
+  __shared__ float gb[LN ? 2 * GBK : 2];
   __shared__ __attribute__((aligned(16))) float red[4 * FT * MT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
     }
     float mean[MT], rstd[MT];
     if constexpr (LN) {
-      for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[1280 + k] = beta[k]; }
+      for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
       // ---- mean: lane partial over its elements, then over the 4 kq lanes, then over the 4 waves through LDS
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         for (int i = 0; i < 4; ++i) { v[i] = xv[u][t][0][i]; v[4 + i] = xv[u][t][1][i]; }
         if constexpr (LN) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gb[k0 + i] + gb[1280 + k0 + i];
+          for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gb[k0 + i] + gb[GBK + k0 + i];
         }
         bf16x8 hi, mid, lo;
         split3(v, hi, mid, lo);
