@@ -113,7 +113,7 @@ def run_vit(args, rank, world, device):
         "metric": "ViT-B/16 images/s (BASELINE.json: Whisper-base audio-sec/s & ViT-B/16 images/s)",
         "value": round(world * B * args.steps / dt, 1),
         "unit": "images/s",
-        "config": {"workload": "ViT-B/16 bf16 forward, batch=256 per GPU, 224x224 (BASELINE configs[1])",
+        "config": {"workload": f"ViT-B/16 bf16 forward, batch={B} per GPU, 224x224 (BASELINE configs[1])",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "collective": "all_gather(outputs)" if world > 1 else "none"},
         "dtype": "bf16",
@@ -163,17 +163,24 @@ def main():
     ap.add_argument("--workload", default="vit", choices=["vit", "whisper"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the BASELINE config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL; "gloo" only to rehearse N > 1 on one GPU)')
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     if args.workload == "vit":
         res = run_vit(args, rank, world, device)
