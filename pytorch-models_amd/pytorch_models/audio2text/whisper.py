@@ -108,6 +108,14 @@ class Whisper(nn.Module):
         """log-mel (B, n_mels, T) + prompt ids (B, P) -> greedy ids (B, P + max_new_tokens)."""
         return self.decoder.generate(self.encoder(x), prompt, max_new_tokens, graph=graph)
 
+    def load_openai_state_dict(self, state_dict) -> None:
+        """OpenAI ``model_state_dict`` (e.g. ``torch.load(path, weights_only=True)["model_state_dict"]``)."""
+        from ..converters import load_openai_whisper
+
+        left = load_openai_whisper(self, state_dict)
+        if left:
+            print(left)
+
     @staticmethod
     def from_openai(model_tag: str, *, pretrained: bool = False, **kwargs) -> "Whisper":
         n_layers, d_model = _SIZES[model_tag]

@@ -100,6 +100,20 @@ class ViT(nn.Module):
         grid = F.interpolate(grid, (g_new, g_new), mode=interpolation_mode)
         self.pe = nn.Parameter(grid.permute(0, 2, 3, 1).flatten(1, 2).to(self.pe.dtype))
 
+    def load_flax_ckpt(self, ckpt, *, big_vision: bool = False, prefix: str = "") -> None:
+        """vision_transformer / big_vision ``.npz`` (local path or mapping; nothing is downloaded)."""
+        from ..converters import load_flax_vit
+
+        left = load_flax_vit(self, ckpt, big_vision=big_vision, prefix=prefix)
+        if left:
+            print(left)
+
+    def load_facebook_state_dict(self, state_dict) -> None:
+        """DeiT-3 / DINO / DINOv2 state_dict (fused qkv, layer scale folded into out_proj / linear2)."""
+        from ..converters import load_facebook_vit
+
+        print(load_facebook_vit(self, state_dict))
+
     @staticmethod
     def _parse(model_tag: str, default_weights: str):
         tag, weights = model_tag.split("_") if "_" in model_tag else (model_tag, default_weights)

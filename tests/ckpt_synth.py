@@ -1,0 +1,152 @@
+"""Synthetic checkpoints in the UPSTREAM formats the reference's converters read (data, built from geometry):
+
+* vision_transformer / big_vision Flax ``.npz`` (reference loader: pytorch_models/image/vit.py:151-200,309-335)
+* facebook / timm ViT state_dict with fused qkv and optional layer scale (vit.py:257-306)
+* OpenAI Whisper state_dict (pytorch_models/audio2text/whisper.py:96-135)
+
+Values come from synthweights.synth_tensor keyed by the upstream key, so the golden generator (which feeds them to
+the reference's converters) and the tests (which feed them to this repo's converters) build identical inputs."""
+import numpy as np
+import torch
+
+from synthweights import synth_tensor
+
+
+def _t(key, shape, seed):
+    return synth_tensor("ckpt:" + key, shape, seed)
+
+
+def flax_vit(n_layers, d, h, patch, n_patches, *, big_vision: bool, cls: bool, map_head: bool, seed=0, prefix=""):
+    hd = d // h
+    if big_vision:
+        ln1, mha, ln2, mlp = "LayerNorm_0", "MultiHeadDotProductAttention_0", "LayerNorm_1", "MlpBlock_0"
+    else:
+        ln1, mha, ln2, mlp = "LayerNorm_0", "MultiHeadDotProductAttention_1", "LayerNorm_2", "MlpBlock_3"
+    sd = {}
+
+    def put(k, shape):
+        sd[prefix + k] = _t(k, shape, seed).numpy()
+
+    if cls:
+        put("cls", (1, 1, d))
+    if big_vision:
+        put("pos_embedding", (1, n_patches, d))
+    else:
+        put("Transformer/posembed_input/pos_embedding", (1, n_patches + 1, d))
+    put("embedding/kernel", (patch, patch, 3, d))
+    put("embedding/bias", (d,))
+    put("Transformer/encoder_norm/scale", (d,))
+    put("Transformer/encoder_norm/bias", (d,))
+
+    def put_mha(base):
+        for nm in ("query", "key", "value"):
+            put(f"{base}/{nm}/kernel", (d, h, hd))
+            put(f"{base}/{nm}/bias", (h, hd))
+        put(f"{base}/out/kernel", (h, hd, d))
+        put(f"{base}/out/bias", (d,))
+
+    for i in range(n_layers):
+        b = f"Transformer/encoderblock_{i}"
+        put(f"{b}/{ln1}/scale", (d,))
+        put(f"{b}/{ln1}/bias", (d,))
+        put_mha(f"{b}/{mha}")
+        put(f"{b}/{ln2}/scale", (d,))
+        put(f"{b}/{ln2}/bias", (d,))
+        put(f"{b}/{mlp}/Dense_0/kernel", (d, 4 * d))
+        put(f"{b}/{mlp}/Dense_0/bias", (4 * d,))
+        put(f"{b}/{mlp}/Dense_1/kernel", (4 * d, d))
+        put(f"{b}/{mlp}/Dense_1/bias", (d,))
+    if map_head:
+        put("MAPHead_0/probe", (1, 1, d))
+        put_mha("MAPHead_0/MultiHeadDotProductAttention_0")
+        put("MAPHead_0/LayerNorm_0/scale", (d,))
+        put("MAPHead_0/LayerNorm_0/bias", (d,))
+        put("MAPHead_0/MlpBlock_0/Dense_0/kernel", (d, 4 * d))
+        put("MAPHead_0/MlpBlock_0/Dense_0/bias", (4 * d,))
+        put("MAPHead_0/MlpBlock_0/Dense_1/kernel", (4 * d, d))
+        put("MAPHead_0/MlpBlock_0/Dense_1/bias", (d,))
+    return sd
+
+
+def facebook_vit(n_layers, d, patch, n_patches, *, pe_has_cls: bool, layer_scale: str | None, seed=0):
+    """layer_scale: None | "gamma" (deit3: gamma_1 / gamma_2) | "ls" (dinov2: ls1.gamma / ls2.gamma)."""
+    sd = {}
+
+    def put(k, shape):
+        sd[k] = _t(k, shape, seed)
+
+    put("patch_embed.proj.weight", (d, 3, patch, patch))
+    put("patch_embed.proj.bias", (d,))
+    put("pos_embed", (1, n_patches + int(pe_has_cls), d))
+    put("cls_token", (1, 1, d))
+    put("norm.weight", (d,))
+    put("norm.bias", (d,))
+    for i in range(n_layers):
+        p = f"blocks.{i}"
+        for nm in ("norm1", "norm2"):
+            put(f"{p}.{nm}.weight", (d,))
+            put(f"{p}.{nm}.bias", (d,))
+        put(f"{p}.attn.qkv.weight", (3 * d, d))
+        put(f"{p}.attn.qkv.bias", (3 * d,))
+        put(f"{p}.attn.proj.weight", (d, d))
+        put(f"{p}.attn.proj.bias", (d,))
+        put(f"{p}.mlp.fc1.weight", (4 * d, d))
+        put(f"{p}.mlp.fc1.bias", (4 * d,))
+        put(f"{p}.mlp.fc2.weight", (d, 4 * d))
+        put(f"{p}.mlp.fc2.bias", (d,))
+        if layer_scale == "gamma":
+            put(f"{p}.gamma_1", (d,))
+            put(f"{p}.gamma_2", (d,))
+        elif layer_scale == "ls":
+            put(f"{p}.ls1.gamma", (d,))
+            put(f"{p}.ls2.gamma", (d,))
+    return sd
+
+
+def openai_whisper(n_layers, d, n_mels, vocab, seed=0):
+    sd = {}
+
+    def put(k, shape):
+        sd[k] = _t(k, shape, seed)
+
+    put("encoder.conv1.weight", (d, n_mels, 3))
+    put("encoder.conv1.bias", (d,))
+    put("encoder.conv2.weight", (d, d, 3))
+    put("encoder.conv2.bias", (d,))
+    put("encoder.positional_embedding", (1500, d))
+    put("decoder.token_embedding.weight", (vocab, d))
+    put("decoder.positional_embedding", (448, d))
+    for side, cross in (("encoder", False), ("decoder", True)):
+        for i in range(n_layers):
+            p = f"{side}.blocks.{i}"
+            for att in ["attn"] + (["cross_attn"] if cross else []):
+                put(f"{p}.{att}.query.weight", (d, d))
+                put(f"{p}.{att}.query.bias", (d,))
+                put(f"{p}.{att}.key.weight", (d, d))  # OpenAI's key projection has no bias
+                put(f"{p}.{att}.value.weight", (d, d))
+                put(f"{p}.{att}.value.bias", (d,))
+                put(f"{p}.{att}.out.weight", (d, d))
+                put(f"{p}.{att}.out.bias", (d,))
+                put(f"{p}.{att}_ln.weight", (d,))
+                put(f"{p}.{att}_ln.bias", (d,))
+            put(f"{p}.mlp.0.weight", (4 * d, d))
+            put(f"{p}.mlp.0.bias", (4 * d,))
+            put(f"{p}.mlp.2.weight", (d, 4 * d))
+            put(f"{p}.mlp.2.bias", (d,))
+            put(f"{p}.mlp_ln.weight", (d,))
+            put(f"{p}.mlp_ln.bias", (d,))
+    put("encoder.ln_post.weight", (d,))
+    put("encoder.ln_post.bias", (d,))
+    put("decoder.ln.weight", (d,))
+    put("decoder.ln.bias", (d,))
+    return sd
+
+
+def state_digest(sd) -> dict:
+    """name -> [sum, sum |x|, position-weighted sum] (fp64) of every tensor of a loaded model."""
+    out = {}
+    for k, v in sd.items():
+        f = v.detach().double().flatten()
+        w = 1.0 + (torch.arange(f.numel(), dtype=torch.float64) % 251) / 251.0
+        out[k] = [f.sum().item(), f.abs().sum().item(), (f * w).sum().item()]
+    return out

@@ -259,9 +259,51 @@ def g_geometry():
     print("geometry.json", os.path.getsize(os.path.join(HERE, "geometry.json")) // 1024, "KiB")
 
 
+def g_converters():
+    """Weight converters: feed synthetic upstream-format checkpoints (tests/ckpt_synth.py) to the
+    reference's loaders and record a digest of every resulting parameter."""
+    import tempfile
+
+    import pytorch_models.image.vit as ref_vit_mod
+
+    sys.path.insert(2, os.path.join(ROOT, "tests"))
+    import ckpt_synth as C
+
+    rec = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        def load_flax(m, ck, **kw):
+            path = os.path.join(tmp, "ck.npz")
+            np.savez(path, **ck)
+            ref_vit_mod.torch_hub_download = lambda url, *a, **k: path  # no network: serve the local synthetic file
+            m.load_flax_ckpt("synthetic.npz", **kw)
+
+        m = ViT(2, 128, 2, 16, img_size=64)
+        load_flax(m, C.flax_vit(2, 128, 2, 16, 16, big_vision=False, cls=True, map_head=False, seed=61))
+        rec["flax_augreg"] = C.state_digest(m.state_dict())
+        m = ViT(2, 128, 2, 16, img_size=64, cls_token=False, pool_type="mha")
+        load_flax(m, C.flax_vit(2, 128, 2, 16, 16, big_vision=True, cls=False, map_head=True, seed=62, prefix="params/img/"),
+                  big_vision=True, prefix="params/img/")
+        rec["flax_siglip"] = C.state_digest(m.state_dict())
+    m = ViT(2, 128, 2, 16, img_size=64)
+    m.load_facebook_state_dict(C.facebook_vit(2, 128, 16, 16, pe_has_cls=False, layer_scale="gamma", seed=63))
+    rec["fb_deit3"] = C.state_digest(m.state_dict())
+    m = ViT(2, 128, 2, 16, img_size=64)
+    m.load_facebook_state_dict(C.facebook_vit(2, 128, 16, 16, pe_has_cls=True, layer_scale="ls", seed=64))
+    rec["fb_dinov2"] = C.state_digest(m.state_dict())
+    m = ViT(2, 128, 2, 16, img_size=64)
+    m.load_facebook_state_dict(C.facebook_vit(2, 128, 16, 16, pe_has_cls=True, layer_scale=None, seed=65))
+    rec["fb_dino"] = C.state_digest(m.state_dict())
+    w = Whisper(100, 2, 64)
+    w.load_openai_state_dict(C.openai_whisper(2, 64, 80, 100, seed=66))
+    rec["openai_whisper"] = C.state_digest(w.state_dict())
+    with open(os.path.join(HERE, "converters.json"), "w") as f:
+        json.dump(rec, f, indent=0, sort_keys=True)
+    print("converters.json", os.path.getsize(os.path.join(HERE, "converters.json")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry"]
+    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters"]
     table = dict(blocks=g_blocks, mha=g_mha, sdpa=g_sdpa_alignment, vit=g_vit, audio=g_audio, whisper=g_whisper,
-                 geometry=g_geometry)
+                 geometry=g_geometry, converters=g_converters)
     for w in which:
         table[w]()

@@ -1,0 +1,112 @@
+"""GPU parity of the shared transformer blocks (rows a1-a5) against the reference's golden vectors and the oracle:
+pre- and post-norm Encoder/Decoder layers, cross-attention, every activation of the MLP table, stacks, and the
+MHA call forms (q / q,k / q,k,v / causal / rectangular causal / unbatched) at head_dim 64.
+
+bf16 tolerance as in test_hip_vit.py: rel-L2 <= 2e-2 vs the fp32 oracle on the same bf16-rounded weights."""
+import pytest
+import torch
+
+from oracle import ref_transformer as RT
+from synthweights import bf16_round_, fill_module, synth_input
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def rel(got, want):
+    got, want = got.float().cpu(), want.float()
+    return ((got - want).norm() / want.norm()).item()
+
+
+def prep(m, seed):
+    fill_module(m, seed)
+    gold_sd = None
+    bf16_round_(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    return m.to(torch.bfloat16).cuda().eval(), sd
+
+
+def bfc(x):
+    return x.to(torch.bfloat16).cuda()
+
+
+def test_layers_pre_post_norm_and_cross_attention(golden):
+    from pytorch_models.transformer import DecoderLayer, EncoderLayer
+
+    g = golden("blocks")
+    d = 64
+    x = synth_input("blk_x", (2, 10, d), 1)
+    mem = synth_input("blk_mem", (2, 7, d), 1)
+    xr, mr = x.to(torch.bfloat16).float(), mem.to(torch.bfloat16).float()
+    for pre in (True, False):
+        for eps in (1e-5, 1e-6):
+            m, sd = prep(EncoderLayer(d, pre_norm=pre, norm_eps=eps), 11)
+            got = m(bfc(x))
+            assert rel(got, RT.encoder_layer(sd, "", 1, xr, pre_norm=pre, eps=eps)) < 2e-2
+            assert rel(got, g[f"enc_pre{int(pre)}_eps{eps}"]) < 3e-2
+            m, sd = prep(DecoderLayer(d, cross_attn=True, pre_norm=pre, norm_eps=eps), 12)
+            got = m(bfc(x), bfc(mem))
+            assert rel(got, RT.decoder_layer(sd, "", 1, xr, mr, pre_norm=pre, eps=eps)) < 2e-2
+            assert rel(got, g[f"dec_pre{int(pre)}_eps{eps}"]) < 3e-2
+    m, sd = prep(DecoderLayer(d, cross_attn=False), 13)
+    assert rel(m(bfc(x)), g["dec_nocross"]) < 3e-2
+
+
+@pytest.mark.parametrize("act", ["gelu", "approximate_gelu", "relu", "silu"])
+def test_mlp_activation_table(golden, act):
+    from pytorch_models.transformer import EncoderLayer
+
+    m, sd = prep(EncoderLayer(64, act=act), 14)
+    x = synth_input("blk_x", (2, 10, 64), 1)
+    got = m(bfc(x))
+    assert rel(got, RT.encoder_layer(sd, "", 1, x.to(torch.bfloat16).float(), act=act)) < 2e-2
+    assert rel(got, golden("blocks")[f"enc_act_{act}"]) < 3e-2
+
+
+def test_stacks(golden):
+    from pytorch_models.transformer import Decoder, Encoder
+
+    g = golden("blocks")
+    x = synth_input("blk_x128", (2, 9, 128), 1)
+    mem = synth_input("blk_mem128", (2, 5, 128), 1)
+    m, _ = prep(Encoder(3, 128, n_heads=2), 15)
+    assert rel(m(bfc(x)), g["encoder3"]) < 3e-2
+    m, _ = prep(Decoder(2, 128, cross_attn=True), 16)
+    assert rel(m(bfc(x), bfc(mem)), g["decoder2"]) < 3e-2
+
+
+def test_mha_call_forms_head_dim_64(golden):
+    """transformer.py:36-45: k defaults to q, v to k; causal is top-left aligned; leading dims are free."""
+    from pytorch_models.transformer import MHA
+
+    d = 128
+    m, sd = prep(MHA(d), 25)  # default head_dim 64 -> 2 heads
+    assert (m.n_heads, m.head_dim) == (2, 64)
+    q = synth_input("mha_q128", (2, 6, d), 2)
+    k = synth_input("mha_k128", (2, 9, d), 2)
+    v = synth_input("mha_v128", (2, 9, d), 2)
+    r = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    assert rel(m(bfc(q)), RT.mha(sd, "", 2, r(q))) < 2e-2
+    assert rel(m(bfc(q), bfc(k)), RT.mha(sd, "", 2, r(q), r(k))) < 2e-2
+    assert rel(m(bfc(q), bfc(k), bfc(v)), RT.mha(sd, "", 2, r(q), r(k), r(v))) < 2e-2
+    assert rel(m(bfc(q), causal=True), RT.mha(sd, "", 2, r(q), causal=True)) < 2e-2
+    assert rel(m(bfc(q), bfc(k), causal=True), RT.mha(sd, "", 2, r(q), r(k), causal=True)) < 2e-2
+    got = m(bfc(q[0]))  # unbatched (L, d)
+    assert got.shape == (6, d) and rel(got, RT.mha(sd, "", 2, r(q[0]))) < 2e-2
+    got = m(bfc(q).view(1, 2, 6, d))  # extra leading dims
+    assert got.shape == (1, 2, 6, d)
+    # the 1-head golden of the reference (d = 64)
+    m1, _ = prep(MHA(64), 21)
+    assert rel(m1(bfc(synth_input("mha_q", (2, 6, 64), 2))), golden("mha")["default_q"]) < 3e-2
+
+
+def test_uncovered_configurations_raise_instead_of_falling_back():
+    from pytorch_models.transformer import MHA
+
+    x = torch.zeros(1, 4, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        MHA(64, n_heads=4).to(torch.bfloat16).cuda()(x)
+    with pytest.raises(NotImplementedError, match="attn_bias"):
+        MHA(64).to(torch.bfloat16).cuda()(x, attn_bias=torch.zeros(1, 1, 4, 4, device="cuda"))
+    with pytest.raises(NotImplementedError, match="bf16"):
+        MHA(64).cuda()(x.float())
