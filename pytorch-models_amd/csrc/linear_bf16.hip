@@ -12,6 +12,12 @@
 // the epilogue packs them into one 8-byte (bf16) or 16-byte (f32) store.
 #include "common.h"
 
+// linear_bf16_wide.hip
+int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
+                               int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
+                               int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -440,6 +446,15 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
                      !((uintptr_t)y & (y_dtype == PM_F32 ? 15 : 7)) && !(bias && ((uintptr_t)bias & 15)) &&
                      !(resid && ((uintptr_t)resid & (resid_dtype == PM_F32 ? 15 : 7)));
   if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || resid_period > (1 << 30)) return PM_EINVAL;
+  hipStream_t st0 = (hipStream_t)stream;
+  if (y_dtype == PM_BF16 && vec_ok && N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && !(resid && resid_dtype != PM_BF16) &&
+      !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) && pm_linear_bf16_wide_applies(M, N, K, act)) {
+    const int rcw = pm_linear_bf16_wide_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
+                                               ldy, M, N, K, act, st0);
+    if (rcw != PM_OK) return rcw;
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+  }
   // 256 x 128 tiles (deep LDS ring, one workgroup per CU) once there are enough of them to fill the chip a few times
   const bool big = (M >= 4096) && ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512 &&
                    (y_dtype == PM_F32 || !vec_ok || (N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15)));

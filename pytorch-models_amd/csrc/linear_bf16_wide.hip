@@ -1,0 +1,214 @@
+// linear_bf16_wide.hip - the wide-N variant of pm_linear_bf16: persistent 256 (tokens) x 256 (features) x 32 tiles.
+// (same operation and reference sites as linear_bf16.hip: pytorch_models/transformer.py:28-31,47-53,59-66)
+//
+// Why a second tile shape.  Every K step a workgroup pulls (BM + BN) * BK * 2 bytes from L2 through its CU's vector
+// memory path (~64 B/clk) and issues 2 * BM * BN * BK flop on the matrix pipe (4096 flop/clk/CU): 256 x 128 tiles need
+// 768 memory-path clocks per 1024 matrix clocks, 256 x 256 tiles 512 per 1024.  With the 256 x 128 kernel the matrix
+// pipe was measured 34 % (K = 768) to 52 % (K = 8192) busy with zero LDS bank conflicts; the load path was the peer
+// limiter.  256 x 256 halves... cuts that pressure by a third, needs 12 instead of 16 fragment reads per 32 MFMAs, and 4
+// instead of 6 LDS-DMA pieces per wave and step.  It is used where there are enough 256 x 256 tiles to balance 256
+// persistent workgroups (QKV, fc1: N = 2304, 3072); N = 768 layers stay on the 256 x 128 kernel (591 tiles would
+// leave a 3-vs-2 tail).
+//
+// Structure (see linear_bf16.hip for the shared ideas): 8 waves as 4 (tokens) x 2 (features), each wave 64 x 128 =
+// 4 x 8 MFMA 16x16x32 tiles (128 accumulator VGPRs); K step = 32 (64-byte rows), 4-stage LDS ring of 32 KiB stages,
+// three steps in flight behind counted vmcnt + raw s_barrier, one stream across all of a workgroup's tiles; 64-byte
+// rows are XOR-swizzled on the LDS-DMA source address (chunk c of row r at c ^ 3*((r >> 3) & 1): conflict-free for the
+// 16-row x 4-chunk fragment read); epilogue = bias / GELU in the accumulator layout, fp32 transposition of 16 x 64
+// blocks through the ring buffer the last step freed, residual + single rounding + 16-byte row-wise stores.
+#include "common.h"
+
+namespace {
+
+constexpr int WBM = 256, WBN = 256, WBK = 32;
+constexpr int WSTAGE = (WBM + WBN) * WBK * 2;  // 32 KiB
+constexpr int WRING = 4;
+constexpr int WGROUP_M = 4;
+
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ (((row >> 3) & 1) * 3); }
+
+__device__ __forceinline__ bf16x8 wread(const char* tile, int row, int chunk) {
+  return *(const bf16x8*)(tile + row * 64 + swz64(row, chunk) * 16);
+}
+
+__device__ __forceinline__ void wtile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int per = WGROUP_M * tiles_n;
+  const int sr = t / per, r = t - sr * per;
+  const int left = tiles_m - sr * WGROUP_M;
+  const int gm = left < WGROUP_M ? left : WGROUP_M;
+  tn = r / gm;
+  tm = sr * WGROUP_M + (r - tn * gm);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+    const bf16* resid, int64_t ldr, int resid_period, bf16* Y, int64_t ldy, int M, int N, int K, int tiles_m, int tiles_n,
+    int x_rows_per_batch, int64_t x_batch_stride) {
+  __shared__ __attribute__((aligned(16))) char smem[WRING * WSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = tiles_m * tiles_n;
+
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+  const int cq = ntiles >> 3, cr = ntiles & 7;
+  const int tbase = xcd * cq + (xcd < cr ? xcd : cr), tcount = cq + (xcd < cr ? 1 : 0);
+  const int my_tiles = local < tcount ? (tcount - local + nloc - 1) / nloc : 0;
+  const int nk = K / WBK;
+  const int P = my_tiles * nk;
+
+  // staging side of the stream (a macro over plain locals: see linear_bf16.hip)
+  int64_t xoff[2], woff[2];
+  int pp = 0, pp_kt = 0, pp_tile = 0, pp_buf = 0;
+#define PM_WSTAGE_NEXT()                                                                                             \
+  if (pp < P) {                                                                                                      \
+    if (pp_kt == 0) {                                                                                                \
+      int tm_, tn_;                                                                                                  \
+      wtile_coords(tbase + local + pp_tile * nloc, tiles_m, tiles_n, tm_, tn_);                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+        const int rt = wave * 32 + i * 16 + (lane >> 2);                                                             \
+        const int chunk = swz64(rt, lane & 3);                                                                       \
+        int gm = tm_ * WBM + rt;                                                                                     \
+        gm = gm < M ? gm : M - 1;                                                                                    \
+        if (x_rows_per_batch > 0) {                                                                                  \
+          const int bb = gm / x_rows_per_batch;                                                                      \
+          xoff[i] = (int64_t)bb * x_batch_stride + (int64_t)(gm - bb * x_rows_per_batch) * ldx + chunk * 8;          \
+        } else {                                                                                                     \
+          xoff[i] = (int64_t)gm * ldx + chunk * 8;                                                                   \
+        }                                                                                                            \
+        int gn = tn_ * WBN + rt;                                                                                     \
+        gn = gn < N ? gn : N - 1;                                                                                    \
+        woff[i] = (int64_t)gn * ldw + chunk * 8;                                                                     \
+      }                                                                                                              \
+    }                                                                                                                \
+    char* xs_ = smem + pp_buf * WSTAGE;                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) glds16(X + xoff[i] + pp_kt * WBK, xs_ + (wave * 32 + i * 16) * 64); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+        glds16(W + woff[i] + pp_kt * WBK, xs_ + WBM * 64 + (wave * 32 + i * 16) * 64);                                \
+    ++pp;                                                                                                            \
+    pp_buf = (pp_buf + 1) & (WRING - 1);                                                                             \
+    if (++pp_kt == nk) { pp_kt = 0; ++pp_tile; }                                                                     \
+  }
+
+  f32x4 acc[8][4];  // [feature subtile j][token subtile i]
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  PM_WSTAGE_NEXT();
+  PM_WSTAGE_NEXT();
+  PM_WSTAGE_NEXT();
+  const int fr = lane & 15, fq = lane >> 4;
+  int buf = 0, kt = 0, ti = 0;
+  for (int pc = 0; pc < P; ++pc) {
+    // step pc landed (this wave's part); up to two younger steps (4 LDS-DMA pieces each) stay in flight
+    const int younger = pp - pc - 1;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's part landed; every wave is past step pc-1: its buffer is free
+    PM_WSTAGE_NEXT();
+    const char* xcur = smem + buf * WSTAGE;
+    const char* wcur = xcur + WBM * 64;
+    {
+      bf16x8 a[8], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = wread(xcur, wm * 64 + i * 16 + fr, fq);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = wread(wcur, wn * 128 + j * 16 + fr, fq);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
+    }
+    const int cbuf = buf;
+    buf = (buf + 1) & (WRING - 1);
+    if (++kt < nk) continue;
+
+    // ---------------- tile finished: epilogue (the next tile's first three K steps are already in flight)
+    kt = 0;
+    int tm, tn;
+    wtile_coords(tbase + local + ti * nloc, tiles_m, tiles_n, tm, tn);
+    ++ti;
+    const int m0 = tm * WBM + wm * 64, n0 = tn * WBN + wn * 128;
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring buffer of this step: 4 KiB of it per wave
+    char* stg = smem + cbuf * WSTAGE + wave * 4096;
+    const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {  // 64-feature halves of the wave's 128 features
+      f32x4 bvec[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int n = n0 + hf * 64 + jj * 16 + fq * 4;
+        bvec[jj] = (bias && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16x8 rv[2];
+        if (resid) {  // coalesced 16-byte loads in the store layout; used after the staging round trip below
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            int mm = m0 + i * 16 + srow + p * 8;
+            mm = mm < M ? mm : M - 1;
+            int nn = n0 + hf * 64 + sch * 8;
+            nn = nn < N ? nn : N - 8;
+            rv[p] = *(const bf16x8*)(resid + (int64_t)(resid_period ? mm % resid_period : mm) * ldr + nn);
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          f32x4 v = acc[hf * 4 + jj][i] + bvec[jj];
+          acc[hf * 4 + jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT, false>(v[r]);
+          *(f32x4*)(stg + fr * 256 + (((4 * jj + fq) ^ fr) * 16)) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int row = srow + p * 8;
+          const f32x4 lo = *(const f32x4*)(stg + row * 256 + (((2 * sch) ^ row) * 16));
+          const f32x4 hi = *(const f32x4*)(stg + row * 256 + (((2 * sch + 1) ^ row) * 16));
+          bf16x8 o;
+          if (resid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = (bf16)(lo[r] + (float)rv[p][r]); o[4 + r] = (bf16)(hi[r] + (float)rv[p][4 + r]); }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = (bf16)lo[r]; o[4 + r] = (bf16)hi[r]; }
+          }
+          const int mm = m0 + i * 16 + row, nn = n0 + hf * 64 + sch * 8;
+          if (mm < M && nn < N) *(bf16x8*)(Y + (int64_t)mm * ldy + nn) = o;  // N % 8 == 0 on this path
+        }
+      }
+    }
+  }
+#undef PM_WSTAGE_NEXT
+}
+
+}  // namespace
+
+// Internal entry (called from linear_bf16.hip's dispatcher; arguments already validated there).
+int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
+                               int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
+                               int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+  const int tiles_m = (int)((M + WBM - 1) / WBM), tiles_n = (int)((N + WBN - 1) / WBN);
+#define PM_WGO(A)                                                                                                      \
+  hipLaunchKernelGGL((linear_bf16_wide_kernel<A>), dim3(256), dim3(512), 0, st, (const bf16*)x, ldx, (const bf16*)w, ldw, \
+                     bias, (const bf16*)resid, ldr, (int)resid_period, (bf16*)y, ldy, (int)M, (int)N, (int)K, tiles_m,  \
+                     tiles_n, (int)x_rows_per_batch, x_batch_stride)
+  if (act == PM_ACT_NONE) PM_WGO(PM_ACT_NONE);
+  else if (act == PM_ACT_GELU) PM_WGO(PM_ACT_GELU);
+  else return PM_EUNSUPPORTED;
+#undef PM_WGO
+  return PM_OK;
+}
+
+bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act) {
+  if (act != PM_ACT_NONE && act != PM_ACT_GELU) return false;
+  if (K % WBK || N % 8) return false;
+  const int64_t tiles = ((M + WBM - 1) / WBM) * ((N + WBN - 1) / WBN);
+  return M >= 4096 && tiles >= 1024;  // >= 4 tiles per persistent workgroup: the 256 x 256 tail stays below ~10 %
+}

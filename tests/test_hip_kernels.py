@@ -88,6 +88,24 @@ def test_linear_strided_views_and_inplace_residual(ops):
     close_bf16(acc, want)
 
 
+@pytest.mark.parametrize("act,with_resid", [("none", False), ("gelu", False), ("none", True)])
+def test_linear_wide_256x256_kernel(ops, act, with_resid):
+    """>= 1024 tiles of 256 x 256 take the wide persistent kernel: ragged M and N, K = 4 steps of 32, every epilogue."""
+    M, N, K = 70000, 1032, 128
+    x = bf(synth_input("lw_x", (M, K), 60))
+    w = bf(synth_input("lw_w", (N, K), 61, scale=0.1))
+    b = synth_input("lw_b", (N,), 62, scale=0.1)
+    r = bf(synth_input("lw_r", (M, N), 63)) if with_resid else None
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), act=act, resid=r.cuda() if with_resid else None)
+    idx = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (400,), generator=torch.Generator().manual_seed(1))])
+    want = x[idx].float() @ w.float().T + b
+    want = want if act == "none" else RT.activation(want, act)
+    if with_resid:
+        want = want + r[idx].float()
+    close_bf16(got[idx.cuda()], want)
+    assert torch.isfinite(got.float()).all()
+
+
 def test_linear_rejects_unsupported(ops):
     x = torch.zeros(4, 72, dtype=torch.bfloat16, device="cuda")
     w = torch.zeros(8, 72, dtype=torch.bfloat16, device="cuda")
