@@ -65,13 +65,19 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
         for _ in range(args.warmup):
             step()
         sync(world)
-        ops.LAUNCH_LOG = {} if rank == 0 else None
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync(world)
         dt = time.perf_counter() - t0
-        log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+        log = None
+        if rank == 0:  # per-kernel event timing of the eager (front end + encoder) launches, outside the timed region
+            ops.LAUNCH_LOG = {}
+            for _ in range(args.steps):
+                dec.rebind(m.encoder(pre(wave)), prompt)
+            torch.cuda.synchronize()
+            log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+        sync(world)
     dt = max_over_ranks(dt, world, device)
     res = {
         "metric": "Whisper-base audio-sec/s (BASELINE.json: Whisper-base audio-sec/s & ViT-B/16 images/s)",
