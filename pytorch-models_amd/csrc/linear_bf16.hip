@@ -303,6 +303,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
         for (int i = 0; i < 4; ++i) b[s][i] = read_frag(xcur, wm * 64 + i * 16 + fr, s * 4 + fq);
       }
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][j], b[s][i], acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     const int cbuf = buf;
     buf = buf == 2 ? 0 : buf + 1;

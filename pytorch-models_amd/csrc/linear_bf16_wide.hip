@@ -119,10 +119,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = wread(wcur, wn * 128 + j * 16 + fr, fq);
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     const int cbuf = buf;
     buf = (buf + 1) & (WRING - 1);
