@@ -72,6 +72,16 @@ int pm_attention_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t,
                       void* o, int64_t o_stride_b, int64_t o_stride_t,
                       int64_t B, int64_t H, int64_t Lq, int64_t Lk, int causal, void* stream);
 
+/* pm_attention_bf16 with the additive attn_mask of transformer.py:52 (`attn_bias`: T5 / MaxViT style relative position
+ * bias): scores + bias[b, h, i, j] before the softmax.  bias: f32, addressed bias + b*stride_b + h*stride_h + i*stride_q + j
+ * (stride 0 = broadcast over batch / heads); -inf entries mask keys (a fully masked row yields NaN, like torch). */
+int pm_attention_bias_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t,
+                           const void* k, int64_t k_stride_b, int64_t k_stride_t,
+                           const void* v, int64_t v_stride_b, int64_t v_stride_t,
+                           void* o, int64_t o_stride_b, int64_t o_stride_t,
+                           int64_t B, int64_t H, int64_t Lq, int64_t Lk, int causal, const float* bias,
+                           int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream);
+
 /* ViT token assembly (vit.py:78-81): Conv2d(3, d, P, stride P) on fp32 NCHW images, flatten,
  * transpose, + pe, prepend cls - im2col-free.  imgs: f32 (N,3,Himg,Wimg); w: bf16 (d, 3*P*P)
  * (the Conv2d weight viewed 2-D); bias: f32 (d); pe: f32 (L, d); cls: f32 (d) or NULL;

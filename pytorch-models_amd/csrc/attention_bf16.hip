@@ -27,12 +27,13 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const char* p0, const char* p1) {
   return u.v;
 }
 
-template <bool CAUSAL>
+template <bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q, int64_t qsb, int64_t qst,
                                                      const bf16* __restrict__ K, int64_t ksb, int64_t kst,
                                                      const bf16* __restrict__ V, int64_t vsb, int64_t vst,
                                                      bf16* __restrict__ O, int64_t osb, int64_t ost, int H, int Lq,
-                                                     int Lk, int nqb) {
+                                                     int Lk, int nqb, const float* __restrict__ bias, int64_t bsb,
+                                                     int64_t bsh, int64_t bsq) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K, V]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
 
   const bool wave_live = q0 + wave * 32 < Lq;
+  const float* bias_row = BIAS ? bias + (int64_t)b * bsb + (int64_t)h * bsh + (int64_t)qi_ld * bsq : nullptr;
   load_tile(0);
   write_tile(smem);
   __syncthreads();
@@ -134,6 +136,10 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
       for (int i = 0; i < 16; ++i) {
         if (kb == 1 && !kb1) continue;
         float v = sc[kb][i] * c;
+        if constexpr (BIAS) {  // additive attn_bias[b, h, q, k] (strides may be 0 = broadcast), natural-log units
+          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);
+          if (key < Lk) v = fmaf(bias_row[key], 1.4426950408889634f, v);
+        }
         if (tail || diag) {
           const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);
           if (key >= Lk || (CAUSAL && key > qi)) v = -1e30f;
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
 
 }  // namespace
 
-extern "C" int pm_attention_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k,
-                                 int64_t k_stride_b, int64_t k_stride_t, const void* v, int64_t v_stride_b,
-                                 int64_t v_stride_t, void* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
-                                 int64_t H, int64_t Lq, int64_t Lk, int causal, void* stream) {
+static int attention_impl(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k, int64_t k_stride_b,
+                          int64_t k_stride_t, const void* v, int64_t v_stride_b, int64_t v_stride_t, void* o,
+                          int64_t o_stride_b, int64_t o_stride_t, int64_t B, int64_t H, int64_t Lq, int64_t Lk, int causal,
+                          const float* bias, int64_t bsb, int64_t bsh, int64_t bsq, void* stream) {
   if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0) return PM_EINVAL;
   if (B == 0 || Lq == 0) return PM_OK;
   if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 8) return PM_EALIGN;
@@ -214,18 +220,38 @@ extern "C" int pm_attention_bf16(const void* q, int64_t q_stride_b, int64_t q_st
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return PM_EALIGN;
   if ((uintptr_t)o & 7) return PM_EALIGN;
   if (Lq > (1 << 24) || Lk > (1 << 24)) return PM_EINVAL;
+  if (bias && (bsb < 0 || bsh < 0 || bsq < Lk)) return PM_EINVAL;
   const int nqb = (int)((Lq + 127) / 128);
   const int64_t nblk = B * H * nqb;
   if (nblk > 0x7fffffff) return PM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (causal)
-    hipLaunchKernelGGL((attn_fwd_hd64<true>), dim3((unsigned)nblk), dim3(256), 0, st, (const bf16*)q, q_stride_b,
-                       q_stride_t, (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t,
-                       (bf16*)o, o_stride_b, o_stride_t, (int)H, (int)Lq, (int)Lk, nqb);
-  else
-    hipLaunchKernelGGL((attn_fwd_hd64<false>), dim3((unsigned)nblk), dim3(256), 0, st, (const bf16*)q, q_stride_b,
-                       q_stride_t, (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t,
-                       (bf16*)o, o_stride_b, o_stride_t, (int)H, (int)Lq, (int)Lk, nqb);
+#define PM_ATT(C_, B_)                                                                                                   \
+  hipLaunchKernelGGL((attn_fwd_hd64<C_, B_>), dim3((unsigned)nblk), dim3(256), 0, st, (const bf16*)q, q_stride_b, q_stride_t, \
+                     (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t, (bf16*)o, o_stride_b,  \
+                     o_stride_t, (int)H, (int)Lq, (int)Lk, nqb, bias, bsb, bsh, bsq)
+  if (causal && bias) PM_ATT(true, true);
+  else if (causal) PM_ATT(true, false);
+  else if (bias) PM_ATT(false, true);
+  else PM_ATT(false, false);
+#undef PM_ATT
   PM_CHECK_LAUNCH();
   return PM_OK;
+}
+
+extern "C" int pm_attention_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k,
+                                 int64_t k_stride_b, int64_t k_stride_t, const void* v, int64_t v_stride_b,
+                                 int64_t v_stride_t, void* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
+                                 int64_t H, int64_t Lq, int64_t Lk, int causal, void* stream) {
+  return attention_impl(q, q_stride_b, q_stride_t, k, k_stride_b, k_stride_t, v, v_stride_b, v_stride_t, o, o_stride_b,
+                        o_stride_t, B, H, Lq, Lk, causal, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int pm_attention_bias_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k,
+                                      int64_t k_stride_b, int64_t k_stride_t, const void* v, int64_t v_stride_b,
+                                      int64_t v_stride_t, void* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
+                                      int64_t H, int64_t Lq, int64_t Lk, int causal, const float* bias,
+                                      int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream) {
+  if (!bias) return PM_EINVAL;
+  return attention_impl(q, q_stride_b, q_stride_t, k, k_stride_b, k_stride_t, v, v_stride_b, v_stride_t, o, o_stride_b,
+                        o_stride_t, B, H, Lq, Lk, causal, bias, bias_stride_b, bias_stride_h, bias_stride_q, stream);
 }

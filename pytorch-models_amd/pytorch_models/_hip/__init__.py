@@ -38,6 +38,7 @@ SIGNATURES = {
     "pm_dec_advance": ([_p, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
     "pm_attention_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
+    "pm_attention_bias_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p, _l, _l, _l, _p], c_int),
     "pm_vit_tokens": ([_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
 }
 

@@ -135,8 +135,6 @@ class MHA(nn.Module):
     def attend(self, q, k=None, v=None, attn_bias=None, causal=False, residual: Tensor | None = None) -> Tensor:
         """forward() plus an optional residual that is added inside the out_proj kernel's epilogue."""
         _require_bf16(q, self.q_proj.weight, "MHA")
-        if attn_bias is not None:
-            raise NotImplementedError("MHA: attn_bias is not covered by the gfx950 attention kernel yet")
         if self.head_dim != 64:
             raise NotImplementedError(f"MHA: head_dim {self.head_dim} != 64 is not covered by the gfx950 attention kernel")
         if self.training and self.dropout > 0.0:
@@ -163,7 +161,21 @@ class MHA(nn.Module):
             qh = qh.expand(*lead, Lq, inner).reshape(-1, Lq, inner)
             kh = kh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
             vh = vh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
-        o = ops.attention(qh, kh, vh, H, causal)
+        bias4 = None
+        if attn_bias is not None:  # additive float bias or boolean keep-mask, broadcastable to (*lead, H, Lq, Lk)
+            ab = attn_bias
+            if ab.dtype == torch.bool:
+                ab = torch.zeros_like(ab, dtype=torch.float32).masked_fill_(~ab, float("-inf"))
+            ab = ab.float()
+            while ab.dim() < 4:
+                ab = ab.unsqueeze(0)
+            if ab.dim() > 4:  # several leading batch dims: flatten them like q
+                ab = ab.expand(*lead, *ab.shape[-3:]).reshape(-1, *ab.shape[-3:])
+            Lk_ = kh.shape[1]
+            bias4 = ab.expand(ab.shape[0], ab.shape[1], Lq, Lk_)
+            if bias4.stride(3) != 1:
+                bias4 = bias4.contiguous()
+        o = ops.attention(qh, kh, vh, H, causal, bias4)
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
         y = ops.linear(o.view(-1, inner), self.out_proj.weight, _f32(self.out_proj, "b", self.out_proj.bias), resid=res2)
         return y.view(*lead, Lq, y.shape[-1])
