@@ -90,6 +90,12 @@ int pm_attention_bias_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t
 int pm_vit_tokens(const float* imgs, const void* w, const float* bias, const float* pe, const float* cls,
                   void* out, int64_t N, int64_t Himg, int64_t Wimg, int64_t P, int64_t d, void* stream);
 
+/* pm_vit_tokens for any patch size P <= 64 (14: DINOv2; 32; 8): w is bf16 (d, ldw) with the 3*P*P real columns
+ * followed by zeros up to ldw >= ceil(3*P*P / 64) * 64.  Scalar gather; not on the benchmark path. */
+int pm_vit_tokens_generic(const float* imgs, const void* w, int64_t ldw, const float* bias, const float* pe,
+                          const float* cls, void* out, int64_t N, int64_t Himg, int64_t Wimg, int64_t P, int64_t d,
+                          void* stream);
+
 /* torch.stft(n_fft, hop, hann window, center=True, reflect, onesided).abs().square() (spectrogram.py:16),
  * optionally followed by the mel filterbank (spectrogram.py:45) and Whisper's log10 (whisper.py:144-145).
  * x: f32, clip b at x + b * x_stride, T samples.  tw_cos / tw_sin: f32 twiddle tables with the window folded in,

@@ -153,6 +153,102 @@ __global__ __launch_bounds__(256, 2) void vit_tokens_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Any patch size (14: DINOv2, 32, 8): same GEMM, but the pixel gather walks (channel, row, column) element by element
+// with scalar loads and the K extent is zero-padded to a multiple of 64 (the packed weight is padded the same way).
+// Not on the benchmark path (every BASELINE config uses patch 16); correctness-first.
+__global__ __launch_bounds__(256, 2) void vit_tokens_generic_kernel(const float* __restrict__ imgs, const bf16* __restrict__ W,
+                                                                    int64_t ldw, const float* __restrict__ bias,
+                                                                    const float* __restrict__ pe,
+                                                                    const float* __restrict__ cls, bf16* __restrict__ out,
+                                                                    int64_t Mtot, int Himg, int Wimg, int Pp, int gw, int Lp,
+                                                                    int d, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];  // single-buffered: A tile, W tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int K = 3 * Pp * Pp, Kpad = (K + BK - 1) / BK * BK;
+  char* atile = smem;
+  char* wtile = smem + TILE_BYTES;
+
+  // thread -> (patch row tid / 2, 32 consecutive k of the step)
+  const int prow = tid >> 1, khalf = tid & 1;
+  int64_t pm = m0 + prow;
+  pm = pm < Mtot ? pm : Mtot - 1;
+  const int64_t nimg = pm / Lp;
+  const int pidx = (int)(pm - nimg * Lp);
+  const int gy = pidx / gw, gx = pidx - gy * gw;
+  const float* pbase = imgs + (nimg * 3 * Himg + (int64_t)gy * Pp) * Wimg + gx * Pp;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < Kpad / BK; ++kt) {
+    const int k0 = kt * BK;
+    stage_w(W, ldw, n0, d, k0, wtile, wave, lane);
+    int k = k0 + khalf * 32;
+    int c = k / (Pp * Pp), rem = k - c * Pp * Pp;
+    int ph = rem / Pp, pw = rem - ph * Pp;
+#pragma unroll 4
+    for (int e = 0; e < 32; ++e) {
+      const float v = (k + e < K) ? pbase[((int64_t)c * Himg + ph) * Wimg + pw] : 0.f;
+      const int kk = khalf * 32 + e;
+      *(bf16*)(atile + prow * 128 + swz_pos(prow, kk >> 3) * 16 + (kk & 7) * 2) = (bf16)v;
+      if (++pw == Pp) { pw = 0; if (++ph == Pp) { ph = 0; ++c; } }
+    }
+    wait_vmcnt0();
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = read_frag(wtile, wn * 64 + j * 16 + fr, s * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = read_frag(atile, wm * 64 + i * 16 + fr, s * 4 + fq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int has_cls = cls != nullptr;
+  const int Lt = Lp + has_cls;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t pmo = m0 + wm * 64 + i * 16 + fr;
+    if (pmo >= Mtot) continue;
+    const int64_t n = pmo / Lp;
+    const int p = (int)(pmo - n * Lp);
+    bf16* orow = out + (n * Lt + has_cls + p) * (int64_t)d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = n0 + wn * 64 + j * 16 + fq * 4;
+      if (f >= d) continue;
+      const f32x4 v = acc[j][i] + *(const f32x4*)(bias + f) + *(const f32x4*)(pe + (int64_t)p * d + f);
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+      *(bf16x4*)(orow + f) = o;
+      if (has_cls && p == 0) {
+        const f32x4 cv = *(const f32x4*)(cls + f);
+        bf16x4 co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) co[r] = (bf16)cv[r];
+        *(bf16x4*)(out + n * Lt * (int64_t)d + f) = co;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int pm_vit_tokens(const float* imgs, const void* w, const float* bias, const float* pe, const float* cls,
@@ -170,6 +266,27 @@ extern "C" int pm_vit_tokens(const float* imgs, const void* w, const float* bias
   if (tiles_m * tiles_n > 0x7fffffff || Lp > (1 << 24)) return PM_EINVAL;
   hipLaunchKernelGGL(vit_tokens_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, imgs,
                      (const bf16*)w, bias, pe, cls, (bf16*)out, Mtot, (int)Himg, (int)Wimg, gw, (int)Lp, (int)d,
+                     (int)tiles_n);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+extern "C" int pm_vit_tokens_generic(const float* imgs, const void* w, int64_t ldw, const float* bias, const float* pe,
+                                     const float* cls, void* out, int64_t N, int64_t Himg, int64_t Wimg, int64_t Pp,
+                                     int64_t d, void* stream) {
+  if (!imgs || !w || !bias || !pe || !out || N < 0 || Himg <= 0 || Wimg <= 0 || d <= 0 || Pp <= 0) return PM_EINVAL;
+  if (N == 0) return PM_OK;
+  if (Himg % Pp || Wimg % Pp || d % 4 || Pp > 64) return PM_EUNSUPPORTED;
+  const int64_t K = 3 * Pp * Pp, Kpad = (K + BK - 1) / BK * BK;
+  if (ldw < Kpad || ldw % 8) return PM_EINVAL;
+  if (((uintptr_t)w | (uintptr_t)bias | (uintptr_t)pe | (uintptr_t)cls) & 15) return PM_EALIGN;
+  if ((uintptr_t)out & 7) return PM_EALIGN;
+  const int gw = (int)(Wimg / Pp), gh = (int)(Himg / Pp);
+  const int64_t Lp = (int64_t)gw * gh, Mtot = N * Lp;
+  const int64_t tiles_m = (Mtot + BM - 1) / BM, tiles_n = (d + BN - 1) / BN;
+  if (tiles_m * tiles_n > 0x7fffffff || Lp > (1 << 24)) return PM_EINVAL;
+  hipLaunchKernelGGL(vit_tokens_generic_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, imgs,
+                     (const bf16*)w, ldw, bias, pe, cls, (bf16*)out, Mtot, (int)Himg, (int)Wimg, (int)Pp, gw, (int)Lp, (int)d,
                      (int)tiles_n);
   PM_CHECK_LAUNCH();
   return PM_OK;

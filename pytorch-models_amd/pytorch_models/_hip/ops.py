@@ -126,16 +126,23 @@ def vit_tokens(imgs: Tensor, w2d: Tensor, bias: Tensor, pe: Tensor, cls: Tensor 
     N, _, H, W = imgs.shape
     d = w2d.shape[0]
     L = (H // patch) * (W // patch)
-    _need(w2d.dtype == torch.bfloat16 and w2d.is_contiguous() and w2d.shape == (d, 3 * patch * patch), "vit_tokens: bad weight")
+    K = 3 * patch * patch
+    _need(w2d.dtype == torch.bfloat16 and w2d.is_contiguous() and w2d.shape[0] == d and w2d.shape[1] >= K, "vit_tokens: bad weight")
     _need(bias.dtype == torch.float32 and bias.numel() == d and bias.is_contiguous(), "vit_tokens: bias f32 (d)")
     _need(pe.dtype == torch.float32 and pe.numel() == L * d and pe.is_contiguous(),
           f"vit_tokens: pe must hold {L} x {d} f32 values (image {H}x{W}, patch {patch}); call resize_pe first")
     if cls is not None:
         _need(cls.dtype == torch.float32 and cls.numel() == d and cls.is_contiguous(), "vit_tokens: cls f32 (d)")
     out = torch.empty((N, L + (cls is not None), d), dtype=torch.bfloat16, device=imgs.device)
-    rc = _launch("vit_tokens", float(imgs.numel() * 4 + out.numel() * 2), lambda: lib().pm_vit_tokens(
-        imgs.data_ptr(), w2d.data_ptr(), bias.data_ptr(), pe.data_ptr(),
-        cls.data_ptr() if cls is not None else None, out.data_ptr(), N, H, W, patch, d, _stream()))
+    if patch == 16 and w2d.shape[1] == K:
+        rc = _launch("vit_tokens", float(imgs.numel() * 4 + out.numel() * 2), lambda: lib().pm_vit_tokens(
+            imgs.data_ptr(), w2d.data_ptr(), bias.data_ptr(), pe.data_ptr(),
+            cls.data_ptr() if cls is not None else None, out.data_ptr(), N, H, W, patch, d, _stream()))
+    else:  # any other patch size: K zero-padded to a multiple of 64 in the packed weight
+        _need(w2d.shape[1] % 64 == 0, "vit_tokens: generic path needs the weight zero-padded to a multiple of 64 columns")
+        rc = _launch("vit_tokens", float(imgs.numel() * 4 + out.numel() * 2), lambda: lib().pm_vit_tokens_generic(
+            imgs.data_ptr(), w2d.data_ptr(), w2d.shape[1], bias.data_ptr(), pe.data_ptr(),
+            cls.data_ptr() if cls is not None else None, out.data_ptr(), N, H, W, patch, d, _stream()))
     check(rc, f"pm_vit_tokens(N={N}, H={H}, W={W}, P={patch}, d={d})")
     return out
 

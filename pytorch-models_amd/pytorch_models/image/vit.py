@@ -79,7 +79,16 @@ class ViT(nn.Module):
         pw = self.patch_embed.weight
         if pw.dtype != torch.bfloat16:
             raise NotImplementedError(f"ViT: only the bf16 path is built (weights are {pw.dtype}); use model.to(torch.bfloat16)")
-        w2d = pw.view(pw.shape[0], -1)
+        if pw.shape[2] == 16:
+            w2d = pw.view(pw.shape[0], -1)
+        else:  # other patch sizes: K = 3*P*P zero-padded to a multiple of 64 (derived copy)
+            def pad():
+                k = 3 * pw.shape[2] * pw.shape[3]
+                w = torch.zeros(pw.shape[0], (k + 63) // 64 * 64, dtype=pw.dtype, device=pw.device)
+                w[:, :k] = pw.detach().reshape(pw.shape[0], -1)
+                return w
+
+            w2d = derived(self, "w2d_pad", (pw,), pad)
         cls = None if self.cls_token is None else _f32(self, "cls", self.cls_token).view(-1)
         return ops.vit_tokens(imgs.float().contiguous(), w2d, _f32(self, "pb", self.patch_embed.bias),
                               _f32(self, "pe", self.pe).view(-1, pw.shape[0]), cls, pw.shape[2])

@@ -107,3 +107,24 @@ def test_vit_b16_full_batch_256_properties():
     torch.testing.assert_close(out[:4], m(xb4), rtol=0, atol=0)
     perm = torch.randperm(256, generator=torch.Generator().manual_seed(1)).cuda()
     torch.testing.assert_close(m(big[perm]), out[perm], rtol=0, atol=0)
+
+
+def test_vit_other_patch_sizes_dinov2_p14(golden):
+    """from_facebook("S/14_dinov2") (patch 14, 518 x 518, L = 1370) and patch 32 / 8 through the generic token kernel."""
+    from pytorch_models.image import ViT
+
+    m, sd, _ = build(lambda V: V.from_facebook("S/14_dinov2"), 35)
+    x = synth_input("vit_dv2", (1, 3, 518, 518), 35)
+    got = m(x.cuda())
+    assert got.shape == (1, 384)
+    check(got, golden("vit")["s14_dinov2_b1"])
+    check(got, RV.forward(sd, RV.geometry_from_facebook("S/14_dinov2"), x))
+    for P, img in ((32, 64), (8, 32)):
+        m = ViT(1, 64, 1, P, img_size=img).eval()
+        fill_module(m, 38)
+        bf16_round_(m)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        x = synth_input(f"vit_p{P}", (3, 3, img, img), 38)
+        t = m.to(torch.bfloat16).cuda().tokens(x.cuda())
+        want = RV.tokens(sd, x.to(torch.bfloat16).float())
+        torch.testing.assert_close(t.float().cpu(), want, rtol=1e-2, atol=2e-2)
