@@ -82,6 +82,16 @@ int pm_attention_bias_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t
                            int64_t B, int64_t H, int64_t Lq, int64_t Lk, int causal, const float* bias,
                            int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream);
 
+/* Attention for head dims other than 64 (8..128, % 8 == 0; e.g. ViT-H's 80): same addressing with h*head_dim head
+ * offsets, optional additive bias (NULL = none), Lk <= 2048.  fp32 VALU, correctness-first, off the benchmark path. */
+int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t,
+                              const void* k, int64_t k_stride_b, int64_t k_stride_t,
+                              const void* v, int64_t v_stride_b, int64_t v_stride_t,
+                              void* o, int64_t o_stride_b, int64_t o_stride_t,
+                              int64_t B, int64_t H, int64_t Lq, int64_t Lk, int64_t head_dim, int causal,
+                              const float* bias, int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q,
+                              void* stream);
+
 /* ViT token assembly (vit.py:78-81): Conv2d(3, d, P, stride P) on fp32 NCHW images, flatten,
  * transpose, + pe, prepend cls - im2col-free.  imgs: f32 (N,3,Himg,Wimg); w: bf16 (d, 3*P*P)
  * (the Conv2d weight viewed 2-D); bias: f32 (d); pe: f32 (L, d); cls: f32 (d) or NULL;

@@ -1,0 +1,120 @@
+// attention_generic.hip - scaled dot-product attention for head dims other than 64 (8 .. 128, multiple of 8), e.g. the
+// 80-wide heads of ViT-H (pytorch_models/image/vit.py:106-113: H = (32, 1280, 16)) or 16 / 32-wide heads of small MHAs.
+// (reference: F.scaled_dot_product_attention at pytorch_models/transformer.py:52, same addressing as attention_bf16.hip)
+//
+// Correctness-first and off the benchmark path (every BASELINE config has head_dim 64): fp32 VALU arithmetic, a
+// workgroup handles 8 queries of one (batch, head), scores for all keys parked in LDS (Lk <= 2048), exact softmax.
+#include "common.h"
+
+namespace {
+
+constexpr int GQ = 8, GMAXK = 2048, GMAXD = 128;
+
+__global__ __launch_bounds__(256) void attn_generic_kernel(const bf16* __restrict__ Q, int64_t qsb, int64_t qst,
+                                                           const bf16* __restrict__ K, int64_t ksb, int64_t kst,
+                                                           const bf16* __restrict__ V, int64_t vsb, int64_t vst,
+                                                           bf16* __restrict__ O, int64_t osb, int64_t ost, int H, int Lq,
+                                                           int Lk, int hd, int nqb, int causal,
+                                                           const float* __restrict__ bias, int64_t bsb, int64_t bsh,
+                                                           int64_t bsq, float scale) {
+  __shared__ float sc[GQ * GMAXK];
+  __shared__ float qs[GQ * GMAXD];
+  __shared__ float inv_sum[GQ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb;
+  const int h = bh % H, b = bh / H;
+  const int q0 = qb * GQ;
+  const bf16* Qp = Q + (int64_t)b * qsb + (int64_t)h * hd;
+  const bf16* Kp = K + (int64_t)b * ksb + (int64_t)h * hd;
+  const bf16* Vp = V + (int64_t)b * vsb + (int64_t)h * hd;
+
+  for (int i = tid; i < GQ * hd; i += 256) {
+    const int qq = i / hd, dd = i - qq * hd;
+    const int qi = q0 + qq < Lq ? q0 + qq : Lq - 1;
+    qs[qq * GMAXD + dd] = (float)Qp[(int64_t)qi * qst + dd];
+  }
+  __syncthreads();
+  // ---- scores: one key per thread and pass, dotted with the 8 queries
+  for (int key = tid; key < Lk; key += 256) {
+    float acc[GQ];
+#pragma unroll
+    for (int qq = 0; qq < GQ; ++qq) acc[qq] = 0.f;
+    const bf16* kr = Kp + (int64_t)key * kst;
+    for (int d0 = 0; d0 < hd; d0 += 8) {
+      const bf16x8 kv = *(const bf16x8*)(kr + d0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float kf = (float)kv[e];
+#pragma unroll
+        for (int qq = 0; qq < GQ; ++qq) acc[qq] = fmaf(qs[qq * GMAXD + d0 + e], kf, acc[qq]);
+      }
+    }
+#pragma unroll
+    for (int qq = 0; qq < GQ; ++qq) {
+      const int qi = q0 + qq;
+      float s = acc[qq] * scale;
+      if (bias && qi < Lq) s += bias[(int64_t)b * bsb + (int64_t)h * bsh + (int64_t)qi * bsq + key];
+      if (causal && key > qi) s = -INFINITY;
+      sc[qq * GMAXK + key] = s;
+    }
+  }
+  __syncthreads();
+  // ---- softmax: wave w owns queries 2w, 2w+1
+  for (int qq = wave * 2; qq < wave * 2 + 2; ++qq) {
+    float mx = -INFINITY;
+    for (int k = lane; k < Lk; k += 64) mx = fmaxf(mx, sc[qq * GMAXK + k]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < Lk; k += 64) {
+      const float p = expf(sc[qq * GMAXK + k] - mx);
+      sc[qq * GMAXK + k] = p;
+      sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) inv_sum[qq] = 1.0f / sum;
+  }
+  __syncthreads();
+  // ---- P.V: thread -> (query tid / 32, 4 dims (tid % 32) * 4)
+  const int qq = tid >> 5, d0 = (tid & 31) * 4;
+  if (d0 < hd) {
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int key = 0; key < Lk; ++key) {
+      const float p = sc[qq * GMAXK + key];
+      const bf16x4 vv = *(const bf16x4*)(Vp + (int64_t)key * vst + d0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaf(p, (float)vv[e], o[e]);
+    }
+    const int qi = q0 + qq;
+    if (qi < Lq) {
+      bf16x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (bf16)(o[e] * inv_sum[qq]);
+      *(bf16x4*)(O + (int64_t)b * osb + (int64_t)qi * ost + (int64_t)h * hd + d0) = ov;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k,
+                                         int64_t k_stride_b, int64_t k_stride_t, const void* v, int64_t v_stride_b,
+                                         int64_t v_stride_t, void* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
+                                         int64_t H, int64_t Lq, int64_t Lk, int64_t head_dim, int causal, const float* bias,
+                                         int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream) {
+  if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0 || head_dim <= 0) return PM_EINVAL;
+  if (B == 0 || Lq == 0) return PM_OK;
+  if (head_dim % 8 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
+  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 8) return PM_EALIGN;
+  if ((o_stride_t | o_stride_b) % 4) return PM_EALIGN;
+  if (((uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return PM_EALIGN;
+  if (bias && bias_stride_q < Lk) return PM_EINVAL;
+  const int nqb = (int)((Lq + GQ - 1) / GQ);
+  const int64_t nblk = B * H * nqb;
+  if (nblk > 0x7fffffff) return PM_EINVAL;
+  hipLaunchKernelGGL(attn_generic_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)q, q_stride_b,
+                     q_stride_t, (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t, (bf16*)o,
+                     o_stride_b, o_stride_t, (int)H, (int)Lq, (int)Lk, (int)head_dim, nqb, causal, bias, bias_stride_b,
+                     bias_stride_h, bias_stride_q, 1.0f / sqrtf((float)head_dim));
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}

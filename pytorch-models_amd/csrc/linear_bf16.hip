@@ -23,12 +23,18 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
 
+__device__ __attribute__((aligned(16))) const unsigned short pm_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // Stage a 128-row x 64-col bf16 tile of G into `tile`: each wave copies 32 rows with 4 instructions of
-// 8 rows x 128 B.  off[i] is the element offset of (this lane's row, this lane's swizzled 16-byte chunk).
-__device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, const int64_t (&off)[4], int k0, char* tile,
-                                           int wave) {
+// 8 rows x 128 B.  off[i] is the element offset of (this lane's row, this lane's swizzled 16-byte chunk), kc[i] that
+// chunk's first column; chunks at or beyond K (a K that is not a multiple of 64) are fed from a zero page.
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ G, const int64_t (&off)[4], const int (&kc)[4], int k0,
+                                           int K, char* tile, int wave) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) glds16(G + off[i] + k0, tile + (wave * 32 + i * 8) * 128);
+  for (int i = 0; i < 4; ++i) {
+    const void* src = (k0 + kc[i] < K) ? (const void*)(G + off[i] + k0) : (const void*)pm_zero_page;
+    glds16(src, tile + (wave * 32 + i * 8) * 128);
+  }
 }
 
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int row, int chunk) {
@@ -58,10 +64,12 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(
   // row offsets are K-loop invariants: out-of-range rows are clamped (and masked at the store); rows of x may be
   // addressed in two levels (batch, row-in-batch) so that e.g. a strided conv window walks a padded buffer
   int64_t xoff[4], woff[4];
+  int kc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rt = wave * 32 + i * 8 + (lane >> 3);
     const int chunk = swz_pos(rt, lane & 7);  // involution: position p holds chunk p ^ f(row)
+    kc[i] = chunk * 8;
     int gm = m0 + rt;
     gm = gm < M ? gm : M - 1;
     int gn = n0 + rt;
@@ -74,9 +82,9 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(
     }
     woff[i] = (int64_t)gn * ldw + chunk * 8;
   }
-  const int nk = K / BK;
-  stage_tile(X, xoff, 0, smem, wave);
-  stage_tile(W, woff, 0, smem + TILE_BYTES, wave);
+  const int nk = (K + BK - 1) / BK;
+  stage_tile(X, xoff, kc, 0, K, smem, wave);
+  stage_tile(W, woff, kc, 0, K, smem + TILE_BYTES, wave);
   wait_vmcnt0();
   __syncthreads();
 
@@ -86,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(
     char* wcur = xcur + TILE_BYTES;
     if (kt + 1 < nk) {
       char* xnxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-      stage_tile(X, xoff, (kt + 1) * BK, xnxt, wave);
-      stage_tile(W, woff, (kt + 1) * BK, xnxt + TILE_BYTES, wave);
+      stage_tile(X, xoff, kc, (kt + 1) * BK, K, xnxt, wave);
+      stage_tile(W, woff, kc, (kt + 1) * BK, K, xnxt + TILE_BYTES, wave);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -440,7 +448,7 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   if (M == 0) return PM_OK;
   if (y_dtype != PM_BF16 && y_dtype != PM_F32) return PM_EINVAL;
   if (resid && resid_dtype != PM_BF16 && resid_dtype != PM_F32) return PM_EINVAL;
-  if (K % BK != 0) return PM_EUNSUPPORTED;
+  if (K % 8 != 0) return PM_EUNSUPPORTED;  // 16-byte chunks; a K tail below 64 is zero-filled by the 128 x 128 kernel
   if (ldx < 0 || ldw < K || ldy < N || (resid && ldr < N) || x_rows_per_batch < 0 || resid_period < 0) return PM_EINVAL;
   if (ldx % 8 || ldw % 8 || x_batch_stride % 8) return PM_EALIGN;
   if (((uintptr_t)x | (uintptr_t)w) & 15) return PM_EALIGN;
@@ -458,7 +466,7 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
     return PM_OK;
   }
   // 256 x 128 tiles (deep LDS ring, one workgroup per CU) once there are enough of them to fill the chip a few times
-  const bool big = (M >= 4096) && ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512 &&
+  const bool big = (K % BK == 0) && (M >= 4096) && ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512 &&
                    (y_dtype == PM_F32 || !vec_ok || (N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15)));
   const int tiles_m = (int)((M + (big ? LBM : BM) - 1) / (big ? LBM : BM)), tiles_n = (int)((N + BN - 1) / BN);
   const int64_t nblk = (int64_t)tiles_m * tiles_n;

@@ -39,6 +39,7 @@ SIGNATURES = {
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
     "pm_attention_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
     "pm_attention_bias_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p, _l, _l, _l, _p], c_int),
+    "pm_attention_generic_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _l, _i, _p, _l, _l, _l, _p], c_int),
     "pm_vit_tokens": ([_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_vit_tokens_generic": ([_p, _p, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
 }

@@ -92,28 +92,36 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: tor
 
 
 def attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = False, bias: Tensor | None = None) -> Tensor:
-    """q (B, Lq, H*64), k / v (B, Lk, H*64) bf16 views with unit last stride (e.g. column slices of a packed
-    QKV projection) -> (B, Lq, H*64) bf16, heads already merged.  bias: optional additive f32 (b, h, Lq, Lk) with
-    b in {1, B}, h in {1, H} (size-1 dims broadcast)."""
+    """q (B, Lq, H*hd), k / v (B, Lk, H*hd) bf16 views with unit last stride (e.g. column slices of a packed
+    QKV projection) -> (B, Lq, H*hd) bf16, heads already merged.  bias: optional additive f32 (b, h, Lq, Lk) with
+    b in {1, B}, h in {1, H} (size-1 dims broadcast).  head_dim 64 runs on the MFMA kernel, other head dims
+    (8..128, % 8 == 0) on the generic one."""
     _cuda(q, k, v, bias)
-    _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention: operands must be (B, L, H*64)")
+    _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention: operands must be (B, L, H*hd)")
     B, Lq, D = q.shape
     Lk = k.shape[1]
-    _need(D == n_heads * 64 and k.shape == (B, Lk, D) and v.shape == (B, Lk, D), "attention: shape mismatch / head_dim != 64")
+    _need(D % n_heads == 0 and k.shape == (B, Lk, D) and v.shape == (B, Lk, D), "attention: shape mismatch")
+    hd = D // n_heads
     for t in (q, k, v):
         _need(t.dtype == torch.bfloat16 and t.stride(2) == 1, "attention: bf16 operands with unit last stride")
     out = torch.empty((B, Lq, D), dtype=torch.bfloat16, device=q.device)
     args = (q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1), v.data_ptr(), v.stride(0),
             v.stride(1), out.data_ptr(), out.stride(0), out.stride(1), B, n_heads, Lq, Lk, int(causal))
-    if bias is None:
-        rc = _launch("attention_bf16", 4.0 * B * n_heads * Lq * Lk * 64, lambda: lib().pm_attention_bf16(*args, _stream()))
-    else:
+    sb = sh = sq = 0
+    if bias is not None:
         _need(bias.dim() == 4 and bias.dtype == torch.float32 and bias.shape[2:] == (Lq, Lk) and bias.stride(3) == 1
               and bias.shape[0] in (1, B) and bias.shape[1] in (1, n_heads), "attention: bias must be f32 (1|B, 1|H, Lq, Lk)")
         sb = 0 if bias.shape[0] == 1 else bias.stride(0)
         sh = 0 if bias.shape[1] == 1 else bias.stride(1)
+        sq = bias.stride(2)
+    if hd != 64:
+        rc = _launch("attention_generic", 4.0 * B * n_heads * Lq * Lk * hd, lambda: lib().pm_attention_generic_bf16(
+            *args[:16], hd, int(causal), bias.data_ptr() if bias is not None else None, sb, sh, sq, _stream()))
+    elif bias is None:
+        rc = _launch("attention_bf16", 4.0 * B * n_heads * Lq * Lk * 64, lambda: lib().pm_attention_bf16(*args, _stream()))
+    else:
         rc = _launch("attention_bf16", 4.0 * B * n_heads * Lq * Lk * 64, lambda: lib().pm_attention_bias_bf16(
-            *args, bias.data_ptr(), sb, sh, bias.stride(2), _stream()))
+            *args, bias.data_ptr(), sb, sh, sq, _stream()))
     check(rc, f"pm_attention_bf16(B={B}, H={n_heads}, Lq={Lq}, Lk={Lk})")
     return out
 

@@ -135,11 +135,11 @@ class MHA(nn.Module):
     def attend(self, q, k=None, v=None, attn_bias=None, causal=False, residual: Tensor | None = None) -> Tensor:
         """forward() plus an optional residual that is added inside the out_proj kernel's epilogue."""
         _require_bf16(q, self.q_proj.weight, "MHA")
-        if self.head_dim != 64:
-            raise NotImplementedError(f"MHA: head_dim {self.head_dim} != 64 is not covered by the gfx950 attention kernel")
+        if self.head_dim % 8 or self.head_dim > 128:
+            raise NotImplementedError(f"MHA: head_dim {self.head_dim} is not covered by the gfx950 attention kernels (8..128, % 8)")
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("MHA: inference only (attention dropout is not implemented)")
-        H, inner = self.n_heads, self.n_heads * 64
+        H, inner = self.n_heads, self.n_heads * self.head_dim
         Lq = q.shape[-2]
         if k is None and v is None:  # self-attention: one projection over the concatenated q/k/v weight
             lead = q.shape[:-2]

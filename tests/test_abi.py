@@ -29,8 +29,8 @@ def test_host_side_validation_launches_nothing():
     assert L.pm_linear_bf16(None, 0, None, 0, None, None, 0, 0, None, 0, 0, 1, 1, 1, 0, None) == 1  # PM_EINVAL
     buf = ctypes.create_string_buffer(4096)
     p = ctypes.addressof(buf) // 16 * 16 + 16
-    # K not a multiple of 64 -> PM_EUNSUPPORTED
-    assert L.pm_linear_bf16(p, 72, p, 72, None, None, 0, 0, p, 8, 0, 4, 8, 72, 0, None) == 2
+    # K not a multiple of 8 -> PM_EUNSUPPORTED
+    assert L.pm_linear_bf16(p, 72, p, 72, None, None, 0, 0, p, 8, 0, 4, 8, 68, 0, None) == 2
     # misaligned leading dimension -> PM_EALIGN
     assert L.pm_linear_bf16(p, 65, p, 64, None, None, 0, 0, p, 8, 0, 4, 8, 64, 0, None) == 4
     assert L.pm_layernorm(p, 12, 0, p, p, 1e-5, p, 12, 0, 4, 12, None) == 2

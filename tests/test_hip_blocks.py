@@ -126,11 +126,40 @@ def test_mha_attn_bias_forms():
     assert rel(m1(bfc(q1), bfc(k1), attn_bias=b1.cuda()), RT.mha(sd1, "", 1, r(q1), r(k1), attn_bias=b1)) < 2e-2
 
 
+def test_mha_other_head_dims_match_the_reference_goldens(golden):
+    """The reference's own MHA goldens use 4 heads of 16 (and 2 x 16 with n_heads * head_dim < d, 2 x 32 without bias):
+    the generic attention kernel covers them, with every call form."""
+    from pytorch_models.transformer import MHA
+
+    g = golden("mha")
+    d = 64
+    q = synth_input("mha_q", (2, 6, d), 2)
+    k = synth_input("mha_k", (2, 9, d), 2)
+    v = synth_input("mha_v", (2, 9, d), 2)
+    bias = synth_input("mha_bias", (2, 1, 6, 9), 2)
+    m, _ = prep(MHA(d, n_heads=4), 22)
+    assert rel(m(bfc(q)), g["h4_q"]) < 3e-2
+    assert rel(m(bfc(q), bfc(k)), g["h4_qk"]) < 3e-2
+    assert rel(m(bfc(q), bfc(k), bfc(v)), g["h4_qkv"]) < 3e-2
+    assert rel(m(bfc(q), bfc(k), bfc(v), attn_bias=bias.cuda()), g["h4_bias"]) < 3e-2
+    assert rel(m(bfc(q), causal=True), g["h4_causal"]) < 3e-2
+    assert rel(m(bfc(q), bfc(k), causal=True), g["h4_causal_rect"]) < 3e-2
+    assert rel(m(bfc(q[0])), g["h4_unbatched"]) < 3e-2
+    m, _ = prep(MHA(d, n_heads=2, head_dim=16), 23)
+    assert rel(m(bfc(q)), g["h2hd16_q"]) < 3e-2
+    m, _ = prep(MHA(d, head_dim=32, bias=False), 24)
+    assert rel(m(bfc(q), bfc(k)), g["hd32_nobias"]) < 3e-2
+    # ViT-H style 80-wide heads (vit.py:112) at a ViT-like length
+    m, sd = prep(MHA(160, n_heads=2), 28)
+    x = synth_input("mha_h80", (2, 257, 160), 9)
+    assert rel(m(bfc(x)), RT.mha(sd, "", 2, x.to(torch.bfloat16).float())) < 2e-2
+
+
 def test_uncovered_configurations_raise_instead_of_falling_back():
     from pytorch_models.transformer import MHA
 
     x = torch.zeros(1, 4, 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(NotImplementedError, match="head_dim"):
-        MHA(64, n_heads=4).to(torch.bfloat16).cuda()(x)
+        MHA(64, n_heads=16).to(torch.bfloat16).cuda()(x)  # head_dim 4
     with pytest.raises(NotImplementedError, match="bf16"):
         MHA(64).cuda()(x.float())

@@ -106,9 +106,18 @@ def test_linear_wide_256x256_kernel(ops, act, with_resid):
     assert torch.isfinite(got.float()).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(12, 64, 32), (70, 96, 72), (300, 132, 200), (5, 8, 8)])
+def test_linear_k_tail(ops, M, N, K):
+    """K not a multiple of 64 (e.g. an out_proj over n_heads * head_dim = 32): the tail of the last K tile is zero-fed."""
+    x = bf(synth_input("lk_x", (M, K), 64))
+    w = bf(synth_input("lk_w", (N, K), 65, scale=K ** -0.5))
+    b = synth_input("lk_b", (N,), 66, scale=0.1)
+    close_bf16(ops.linear(x.cuda(), w.cuda(), b.cuda()), x.float() @ w.float().T + b)
+
+
 def test_linear_rejects_unsupported(ops):
-    x = torch.zeros(4, 72, dtype=torch.bfloat16, device="cuda")
-    w = torch.zeros(8, 72, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(4, 68, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(8, 68, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError, match="pm_mi355x error 2"):
         ops.linear(x, w)
     with pytest.raises(RuntimeError, match="HIP devices only"):
