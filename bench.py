@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL; "gloo" only to rehearse N > 1 on one GPU)')
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-graph", action="store_true", help="whisper: eager decode launches instead of the captured HIP graph "
+                    "(rocprofv3 --pmc cannot sample graph replays on this stack)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -9,6 +9,13 @@ PEAK_HBM_GBS = 8000.0
 N_NEW, PROMPT = 224, 4  # fixed prompt of 4 ids, max_seq_len // 2 new tokens
 
 
+def _traffic():
+    import json
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "whisper_traffic.json")
+    return round(json.load(open(path))["traffic_bytes_per_launch"]) if os.path.exists(path) else None
+
+
 def cpu_baseline_whisper(cores: int) -> dict:
     """Oracle (kind "port") on the host: same pipeline, 2 clips, full 224-token KV-cached greedy decode."""
     from oracle import ref_spectrogram as RS
@@ -52,12 +59,13 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
     with torch.no_grad():
         memory = m.encoder(pre(wave))
         dec = GreedyDecoder(m.decoder, memory, prompt, N_NEW)
-        dec.run(graph=True)  # builds + captures the step graph once
+        use_graph = not getattr(args, "no_graph", False)
+        dec.run(graph=use_graph)  # builds + captures the step graph once
 
         def step():
             mem = m.encoder(pre(wave))
             dec.rebind(mem, prompt)
-            toks = dec.run(graph=True)
+            toks = dec.run(graph=use_graph)
             if world > 1:
                 dist.all_gather(gathered, toks)
             return toks
@@ -110,7 +118,9 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
         cross_bytes = len(cross) * (2 * B * S * d * 2 + 2 * B * d * 4 + d * d * 2)
         ach = cross_bytes / cross_ms / 1e6
         res["roofline"] = {"bound": "hbm", "kernel": "dec_attn_fused_kernel<false> (LN + q-proj + cross-attention over 1500 keys)", "achieved": round(ach, 1),
-                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": _traffic(),
+                           "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC on the kernel alone, profiles/r01/whisper_traffic.json)",
+                           "algorithmic_bytes_per_launch": cross_bytes // max(len(cross), 1),
                            "launches": len(cross), "avg_launch_us": round(1e3 * cross_ms / len(cross), 2),
                            "note": "timed in an extra eager pass after the timed region (the timed region replays a graph)"}
         res["decode_kernels_eager_ms_per_step"] = {
