@@ -409,20 +409,6 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   const int Lk = SELF ? tpos + 1 : lk_const;
   const int nproj = SELF ? 3 : 1;
 
-  // ---- the K stream does not depend on q: request its first NKU passes (cross block: all 1500 keys = 192 KiB) before
-  // anything else, so HBM streams while the LayerNorm and the projection run.  8 lanes per key, 64 keys per pass.
-  constexpr int NKU = SELF ? 4 : PM_CROSS_NKU;
-  const int c = lane & 7, ks = lane >> 3;
-  const bf16* kb = Kc + b * sb + h * sh + c * 8;
-  const bf16* vb = Vc + b * sb + h * sh + c * 8;
-  const int Lc = SELF ? Lk - 1 : Lk;  // keys read from memory (self: the newest one comes from LDS)
-  bf16x8 kv[NKU];
-#pragma unroll
-  for (int u = 0; u < NKU; ++u) {
-    int key = u * 64 + wave * 8 + ks;
-    key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-    kv[u] = SELF ? *(const bf16x8*)(kb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(kb + key * sk));
-  }
   // ---- projection weights: 8 lanes per output row, lane p owns 16-byte chunks p, p+8, ...
   const int prow = tid >> 3, pl = tid & 7;
   const int nch = d >> 6;  // chunks per lane (d % 64 == 0)
@@ -438,6 +424,20 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       for (int i = 0; i < NCH; ++i)
         if (i < nch) wv[o][i] = *(const bf16x8*)(wr + i * 64);
     }
+  }
+  // ---- the K stream does not depend on q: request its first NKU passes now - AFTER the projection weights, so the
+  // weights are not queued behind it - and let HBM stream while the LayerNorm and the projection run.
+  constexpr int NKU = SELF ? 4 : PM_CROSS_NKU;
+  const int c = lane & 7, ks = lane >> 3;
+  const bf16* kb = Kc + b * sb + h * sh + c * 8;
+  const bf16* vb = Vc + b * sb + h * sh + c * 8;
+  const int Lc = SELF ? Lk - 1 : Lk;  // keys read from memory (self: the newest one comes from LDS)
+  bf16x8 kv[NKU];
+#pragma unroll
+  for (int u = 0; u < NKU; ++u) {
+    int key = u * 64 + wave * 8 + ks;
+    key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
+    kv[u] = SELF ? *(const bf16x8*)(kb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(kb + key * sk));
   }
   // ---- LayerNorm of row b (two-pass from registers)
   const float* xr = x + (int64_t)b * d;
