@@ -54,6 +54,20 @@ int pm_linear_bf16_ex(const void* x, int64_t ldx, int64_t x_rows_per_batch, int6
                       int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
                       void* stream);
 
+/* LayerNorm folded into the GEMMs around it (pre-norm blocks, transformer.py:124-125: x + f(LN(x))).
+ * pm_linear_bf16_ln = pm_linear_bf16_ex plus
+ *  - ln_stats (M, 2) f32 [mean, rstd per input row] and ln_s (N) f32: y = act(rstd*(x w'^T - mean*ln_s) + bias) + resid,
+ *    where the caller passes w' = bf16(gamma (.) w), ln_s[n] = sum_k w'[n][k], bias[n] = b[n] + sum_k beta[k] w[n][k];
+ *  - ln_row_out (M, N/64, 2) f32: per row and 64-feature block, (sum, sum of squares) of the bf16-rounded outputs -
+ *    the partial statistics of the NEXT LayerNorm, reduced by pm_ln_stats_finalize into (mean, rstd).
+ * Served by the persistent kernels only: check pm_linear_ln_supported(M, N, K, act, produce) first (1 = yes). */
+int pm_linear_bf16_ln(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
+                      int64_t ldw, const float* bias, const void* resid, int64_t ldr, int resid_dtype,
+                      int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
+                      const float* ln_stats, const float* ln_s, float* ln_row_out, void* stream);
+int pm_ln_stats_finalize(const float* row_partials, float* stats, int64_t M, int64_t N, float eps, void* stream);
+int pm_linear_ln_supported(int64_t M, int64_t N, int64_t K, int act, int produce);
+
 /* nn.LayerNorm over the last dim (transformer.py:87,90,93; vit.py:69; whisper.py:27,45):
  * y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta, fp32 statistics, biased variance.
  * x: x_dtype (M, d) with row stride ldx; gamma/beta: f32 (d); y: y_dtype.  d % 8 == 0. */

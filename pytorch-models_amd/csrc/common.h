@@ -11,11 +11,28 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 #define PM_LDS __attribute__((address_space(3)))
 #define PM_GLOBAL __attribute__((address_space(1)))
+
+// LayerNorm folded into the GEMMs around it (see linear_bf16.hip, "LayerNorm fold"): all three pointers may be null.
+// Sum over the 8 consecutive lanes of an aligned 8-lane group, result in every lane: two quad_perm DPP steps
+// (xor 1, xor 2) and row_half_mirror (lane i <-> 7 - i crosses the two quads).  VALU only.
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
+struct PmLnFold {
+  const float* stats;  // (M, 2): mean, rstd of each input row -> the epilogue computes rstd * (acc - mean * s[n]) + bias[n]
+  const float* s;      // (N): column sums of the gamma-folded weight
+  float* row_out;      // (M, N / 64, 2): per 64-feature block (sum, sum of squares) of the bf16-rounded OUTPUT rows
+};
 
 #define PM_CHECK_LAUNCH()                                  \
   do {                                                     \

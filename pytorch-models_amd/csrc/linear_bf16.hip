@@ -15,7 +15,7 @@
 // linear_bf16_wide.hip
 int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                                int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
-                               int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t st);
+                               int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, hipStream_t st);
 bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act);
 
 namespace {
@@ -207,7 +207,7 @@ template <int ACT, bool YF32>
 __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
     const void* resid, int64_t ldr, int resid_f32, int resid_period, void* Y, int64_t ldy, int M, int N, int K,
-    int tiles_n, int ntiles, int x_rows_per_batch, int64_t x_batch_stride, int vec_ok) {
+    int tiles_n, int ntiles, int x_rows_per_batch, int64_t x_batch_stride, int vec_ok, PmLnFold ln) {
   __shared__ __attribute__((aligned(16))) char smem[3 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
   const int fr = lane & 15, fq = lane >> 4;
   const bool staged_epi = vec_ok && !YF32 && !(resid && resid_f32);
   bf16x8 rv[4][2];
+  f32x2 lnst[4] = {{0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}};
   int buf = 0, kt = 0, ti = 0;
   for (int pc = 0; pc < P; ++pc) {
     // step pc landed; step pc+1 may stay in flight.  (Exact bookkeeping that also lets the epilogue's stores stay in
@@ -296,6 +297,16 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
           nn = nn < N ? nn : N - 8;
           rv[i][p] = *(const bf16x8*)((const bf16*)resid + (int64_t)(resid_period ? mm % resid_period : mm) * ldr + nn);
         }
+    }
+    if (kt == nk - 1 && staged_epi && ln.stats) {  // LayerNorm fold: (mean, rstd) of this lane's rows m0 + 16 i + fr
+      int tm_r, tn_r;
+      tile_coords(tbase + local + ti * nloc, tiles_m, tiles_n, tm_r, tn_r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int mr = tm_r * LBM + wm * 64 + i * 16 + fr;
+        mr = mr < M ? mr : M - 1;
+        lnst[i] = *(const f32x2*)(ln.stats + 2 * (int64_t)mr);
+      }
     }
     const char* xcur = smem + buf * STAGE_BYTES;
     const char* wcur = xcur + LBM * 128;
@@ -348,17 +359,21 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
       __builtin_amdgcn_s_barrier();
       char* stg = smem + cbuf * STAGE_BYTES + wave * 4096;
       const int srow = lane >> 3, sch = lane & 7;  // row-wise side: 8 lanes x 8 features per 64-feature row segment
-      f32x4 bvec[4];  // this lane's bias values, loaded once per tile (not per 16-token chunk)
+      f32x4 bvec[4], svec[4];  // this lane's bias (and LN-fold column sum) values, loaded once per tile
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + j * 16 + fq * 4;
         bvec[j] = (bias && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        svec[j] = (ln.stats && n < N) ? *(const f32x4*)(ln.s + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        const float mu = lnst[i][0], rstd = lnst[i][1];  // (0, 1) without the LayerNorm fold
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 v = acc[j][i] + bvec[j];
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, acc[j][i][r] - mu * svec[j][r], bvec[j][r]);
           acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT, false>(v[r]);
@@ -379,6 +394,15 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
             for (int r = 0; r < 4; ++r) { o[r] = (bf16)lo[r]; o[4 + r] = (bf16)hi[r]; }
           }
           const int mm = m0 + i * 16 + row, nn = n0 + sch * 8;
+          if (ln.row_out) {  // (sum, sum of squares) of this row's 64 ROUNDED outputs: the next LayerNorm's partials
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const float f = (float)o[r]; s1 += f; s2 = fmaf(f, f, s2); }
+            s1 = sum8_dpp(s1);  // the row's 8 lanes (sch 0..7): DPP adds, no LDS traffic
+            s2 = sum8_dpp(s2);
+            if (sch == 0 && mm < M && nn < N)
+              *(f32x2*)(ln.row_out + ((int64_t)mm * (N >> 6) + (n0 >> 6)) * 2) = f32x2{s1, s2};
+          }
 #ifdef PM_ABLATE_STORES  // experiment only
           asm volatile("" ::"v"(o));
 #else
@@ -417,11 +441,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
 template <bool YF32>
 int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int64_t ldx, const bf16* W, int64_t ldw,
                const float* bias, const void* resid, int64_t ldr, int resid_f32, int resid_period, void* Y, int64_t ldy,
-               int M, int N, int K, int tiles_n, int xrpb, int64_t xbs, int vec_ok) {
+               int M, int N, int K, int tiles_n, int xrpb, int64_t xbs, int vec_ok, PmLnFold ln) {
 #define PM_GO(A)                                                                                                       \
   if (big)                                                                                                             \
     hipLaunchKernelGGL((linear_bf16_persist_kernel<A, YF32>), dim3(PERSIST_WGS), dim3(512), 0, st, X, ldx, W, ldw, bias, \
-                       resid, ldr, resid_f32, resid_period, Y, ldy, M, N, K, tiles_n, (int)grid.x, xrpb, xbs, vec_ok); \
+                       resid, ldr, resid_f32, resid_period, Y, ldy, M, N, K, tiles_n, (int)grid.x, xrpb, xbs, vec_ok, ln); \
   else                                                                                                                 \
     hipLaunchKernelGGL((linear_bf16_kernel<A, YF32>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, resid, ldr,          \
                        resid_f32, resid_period, Y, ldy, M, N, K, tiles_n, xrpb, xbs, vec_ok);                          \
@@ -443,8 +467,11 @@ int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int6
 static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                        int64_t ldw, const float* bias, const void* resid, int64_t ldr, int resid_dtype,
                        int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
-                       void* stream) {
+                       PmLnFold ln, void* stream) {
   if (!x || !w || !y || M < 0 || N <= 0 || K <= 0) return PM_EINVAL;
+  const bool want_ln = ln.stats || ln.row_out;
+  if ((ln.stats == nullptr) != (ln.s == nullptr)) return PM_EINVAL;
+  if (ln.row_out && N % 64) return PM_EUNSUPPORTED;
   if (M == 0) return PM_OK;
   if (y_dtype != PM_BF16 && y_dtype != PM_F32) return PM_EINVAL;
   if (resid && resid_dtype != PM_BF16 && resid_dtype != PM_F32) return PM_EINVAL;
@@ -459,8 +486,9 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   hipStream_t st0 = (hipStream_t)stream;
   if (y_dtype == PM_BF16 && vec_ok && N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && !(resid && resid_dtype != PM_BF16) &&
       !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) && pm_linear_bf16_wide_applies(M, N, K, act)) {
+    if (ln.row_out) return PM_EUNSUPPORTED;  // row partials are produced by the 256 x 128 kernel (N = d_model layers)
     const int rcw = pm_linear_bf16_wide_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
-                                               ldy, M, N, K, act, st0);
+                                               ldy, M, N, K, act, ln, st0);
     if (rcw != PM_OK) return rcw;
     PM_CHECK_LAUNCH();
     return PM_OK;
@@ -468,6 +496,8 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   // 256 x 128 tiles (deep LDS ring, one workgroup per CU) once there are enough of them to fill the chip a few times
   const bool big = (K % BK == 0) && (M >= 4096) && ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512 &&
                    (y_dtype == PM_F32 || !vec_ok || (N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15)));
+  const bool staged = big && y_dtype == PM_BF16 && vec_ok && !(resid && resid_dtype == PM_F32);
+  if (want_ln && !staged) return PM_EUNSUPPORTED;  // the LayerNorm fold lives in the persistent kernels' staged epilogue
   const int tiles_m = (int)((M + (big ? LBM : BM) - 1) / (big ? LBM : BM)), tiles_n = (int)((N + BN - 1) / BN);
   const int64_t nblk = (int64_t)tiles_m * tiles_n;
   if (nblk > 0x7fffffff) return PM_EINVAL;
@@ -476,10 +506,10 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   int rc = (y_dtype == PM_F32)
                ? launch_act<true>(act, big, grid, st, (const bf16*)x, ldx, (const bf16*)w, ldw, bias, resid, ldr,
                                   resid_dtype == PM_F32, (int)resid_period, y, ldy, (int)M, (int)N, (int)K, tiles_n,
-                                  (int)x_rows_per_batch, x_batch_stride, vec_ok)
+                                  (int)x_rows_per_batch, x_batch_stride, vec_ok, ln)
                : launch_act<false>(act, big, grid, st, (const bf16*)x, ldx, (const bf16*)w, ldw, bias, resid, ldr,
                                    resid_dtype == PM_F32, (int)resid_period, y, ldy, (int)M, (int)N, (int)K, tiles_n,
-                                   (int)x_rows_per_batch, x_batch_stride, vec_ok);
+                                   (int)x_rows_per_batch, x_batch_stride, vec_ok, ln);
   if (rc != PM_OK) return rc;
   PM_CHECK_LAUNCH();
   return PM_OK;
@@ -489,7 +519,7 @@ extern "C" int pm_linear_bf16(const void* x, int64_t ldx, const void* w, int64_t
                               const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype,
                               int64_t M, int64_t N, int64_t K, int act, void* stream) {
   if (ldx < K) return PM_EINVAL;
-  return linear_impl(x, ldx, 0, 0, w, ldw, bias, resid, ldr, resid_dtype, 0, y, ldy, y_dtype, M, N, K, act, stream);
+  return linear_impl(x, ldx, 0, 0, w, ldw, bias, resid, ldr, resid_dtype, 0, y, ldy, y_dtype, M, N, K, act, PmLnFold{}, stream);
 }
 
 extern "C" int pm_linear_bf16_ex(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
@@ -497,5 +527,58 @@ extern "C" int pm_linear_bf16_ex(const void* x, int64_t ldx, int64_t x_rows_per_
                                  int resid_dtype, int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M,
                                  int64_t N, int64_t K, int act, void* stream) {
   return linear_impl(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_dtype, resid_period, y, ldy,
-                     y_dtype, M, N, K, act, stream);
+                     y_dtype, M, N, K, act, PmLnFold{}, stream);
+}
+
+// ---- LayerNorm fold -------------------------------------------------------------------------------------------
+// A pre-norm block computes y = LN(x) W^T + b.  With W' = bf16(gamma (.) W), s[n] = sum_k W'[n][k] and
+// c[n] = b[n] + sum_k beta[k] W[n][k] this is rstd[m] * (x W'^T - mean[m] * s[n]) + c[n]: the GEMM runs on the RAW
+// residual stream and the normalisation is two fma per output in its epilogue.  mean / rstd come from per-row partial
+// sums that the PRODUCER of x (the previous out_proj / linear2 GEMM) emits from its own epilogue (ln_row_out), reduced
+// by pm_ln_stats_finalize.  The LayerNorm kernel, its write of LN(x) and the re-read of it disappear.
+extern "C" int pm_linear_bf16_ln(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
+                                 const void* w, int64_t ldw, const float* bias, const void* resid, int64_t ldr,
+                                 int resid_dtype, int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M,
+                                 int64_t N, int64_t K, int act, const float* ln_stats, const float* ln_s,
+                                 float* ln_row_out, void* stream) {
+  PmLnFold ln{ln_stats, ln_s, ln_row_out};
+  return linear_impl(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_dtype, resid_period, y, ldy,
+                     y_dtype, M, N, K, act, ln, stream);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                               int64_t M, int np, float inv_n, float eps) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = 0; p < np; ++p) {  // fixed order: deterministic
+    s1 += part[(m * np + p) * 2];
+    s2 += part[(m * np + p) * 2 + 1];
+  }
+  const float mean = s1 * inv_n;
+  const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+  stats[2 * m] = mean;
+  stats[2 * m + 1] = rsqrtf(var + eps);
+}
+}  // namespace
+
+extern "C" int pm_ln_stats_finalize(const float* row_partials, float* stats, int64_t M, int64_t N, float eps, void* stream) {
+  if (!row_partials || !stats || M < 0 || N <= 0) return PM_EINVAL;
+  if (M == 0) return PM_OK;
+  if (N % 64) return PM_EUNSUPPORTED;
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row_partials,
+                     stats, M, (int)(N / 64), 1.0f / (float)N, eps);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+/* 1 if pm_linear_bf16_ln can serve this shape (as a consumer of ln_stats when produce == 0, as a producer of
+ * ln_row_out when produce == 1), else 0: callers fall back to pm_layernorm + pm_linear_bf16. */
+extern "C" int pm_linear_ln_supported(int64_t M, int64_t N, int64_t K, int act, int produce) {
+  if (K % 64 || N % 8 || M < 4096) return 0;
+  const bool wide = pm_linear_bf16_wide_applies(M, N, K, act);
+  const bool big = ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512;
+  if (produce) return (!wide && big && N % 64 == 0) ? 1 : 0;
+  return (wide || big) ? 1 : 0;
 }

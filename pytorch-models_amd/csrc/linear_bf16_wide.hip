@@ -44,7 +44,7 @@ template <int ACT>
 __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
     const bf16* resid, int64_t ldr, int resid_period, bf16* Y, int64_t ldy, int M, int N, int K, int tiles_m, int tiles_n,
-    int x_rows_per_batch, int64_t x_batch_stride) {
+    int x_rows_per_batch, int64_t x_batch_stride, PmLnFold ln) {
   __shared__ __attribute__((aligned(16))) char smem[WRING * WSTAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
   PM_WSTAGE_NEXT();
   const int fr = lane & 15, fq = lane >> 4;
   int buf = 0, kt = 0, ti = 0;
+  f32x2 lnst[4] = {{0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}};
   for (int pc = 0; pc < P; ++pc) {
     // step pc landed (this wave's part); up to two younger steps (4 LDS-DMA pieces each) stay in flight
     const int younger = pp - pc - 1;
@@ -110,6 +111,18 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's part landed; every wave is past step pc-1: its buffer is free
     PM_WSTAGE_NEXT();
+    if (kt == nk - 1 && ln.stats) {
+      // LayerNorm fold, last K step of the tile: request (mean, rstd) of this lane's four token rows
+      // (m0 + 16 i + fr) now, so the latency hides under this step's MFMAs instead of stalling the epilogue
+      int tm_r, tn_r;
+      wtile_coords(tbase + local + ti * nloc, tiles_m, tiles_n, tm_r, tn_r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int mr = tm_r * WBM + wm * 64 + i * 16 + fr;
+        mr = mr < M ? mr : M - 1;
+        lnst[i] = *(const f32x2*)(ln.stats + 2 * (int64_t)mr);
+      }
+    }
     const char* xcur = smem + buf * WSTAGE;
     const char* wcur = xcur + WBM * 64;
     {
@@ -141,14 +154,16 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
     const int srow = lane >> 3, sch = lane & 7;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {  // 64-feature halves of the wave's 128 features
-      f32x4 bvec[4];
+      f32x4 bvec[4], svec[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int n = n0 + hf * 64 + jj * 16 + fq * 4;
         bvec[jj] = (bias && n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        svec[jj] = (ln.stats && n < N) ? *(const f32x4*)(ln.s + n) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        const float mu = lnst[i][0], rstd = lnst[i][1];  // (0, 1) without the LayerNorm fold
         bf16x8 rv[2];
         if (resid) {  // coalesced 16-byte loads in the store layout; used after the staging round trip below
 #pragma unroll
@@ -162,7 +177,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          f32x4 v = acc[hf * 4 + jj][i] + bvec[jj];
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, acc[hf * 4 + jj][i][r] - mu * svec[jj][r], bvec[jj][r]);
           acc[hf * 4 + jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT, false>(v[r]);
@@ -195,12 +212,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
 // Internal entry (called from linear_bf16.hip's dispatcher; arguments already validated there).
 int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                                int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
-                               int64_t ldy, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+                               int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, hipStream_t st) {
   const int tiles_m = (int)((M + WBM - 1) / WBM), tiles_n = (int)((N + WBN - 1) / WBN);
 #define PM_WGO(A)                                                                                                      \
   hipLaunchKernelGGL((linear_bf16_wide_kernel<A>), dim3(256), dim3(512), 0, st, (const bf16*)x, ldx, (const bf16*)w, ldw, \
                      bias, (const bf16*)resid, ldr, (int)resid_period, (bf16*)y, ldy, (int)M, (int)N, (int)K, tiles_m,  \
-                     tiles_n, (int)x_rows_per_batch, x_batch_stride)
+                     tiles_n, (int)x_rows_per_batch, x_batch_stride, ln)
   if (act == PM_ACT_NONE) PM_WGO(PM_ACT_NONE);
   else if (act == PM_ACT_GELU) PM_WGO(PM_ACT_GELU);
   else return PM_EUNSUPPORTED;

@@ -25,6 +25,9 @@ SIGNATURES = {
     "pm_strerror": ([_i], c_char_p),
     "pm_linear_bf16": ([_p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
     "pm_linear_bf16_ex": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
+    "pm_linear_bf16_ln": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p, _p, _p, _p], c_int),
+    "pm_ln_stats_finalize": ([_p, _p, _l, _l, _f, _p], c_int),
+    "pm_linear_ln_supported": ([_l, _l, _l, _i, _i], c_int),
     "pm_stft_mel": ([_p, _l, _l, _l, _p, _p, _l, _l, _l, _i, _p, _p, _p, _l, _p, _p, _p], c_int),
     "pm_logmel_finalize": ([_p, _p, _l, _l, _p], c_int),
     "pm_whisper_stem1": ([_p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),

@@ -52,9 +52,26 @@ def _cuda(*ts: Tensor) -> None:
             )
 
 
+def linear_ln_supported(M: int, N: int, K: int, act: str, produce: bool) -> bool:
+    return bool(lib().pm_linear_ln_supported(M, N, K, ACT[act], int(produce)))
+
+
+def ln_stats_finalize(partials: Tensor, N: int, eps: float) -> Tensor:
+    """(M, N/64, 2) row partials [sum, sum of squares] -> (M, 2) [mean, rstd]."""
+    M = partials.shape[0]
+    stats = torch.empty((M, 2), dtype=torch.float32, device=partials.device)
+    rc = _launch("ln_stats_finalize", float(partials.numel() * 4), lambda: lib().pm_ln_stats_finalize(
+        partials.data_ptr(), stats.data_ptr(), M, N, float(eps), _stream()))
+    check(rc, "pm_ln_stats_finalize")
+    return stats
+
+
 def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none", resid: Tensor | None = None,
-           out_dtype: torch.dtype = torch.bfloat16, out: Tensor | None = None) -> Tensor:
-    """y = act(x @ w.T + bias) + resid.  x (M, K) bf16, w (N, K) bf16, bias f32 (N), resid (M, N) bf16|f32."""
+           out_dtype: torch.dtype = torch.bfloat16, out: Tensor | None = None, ln_stats: Tensor | None = None,
+           ln_s: Tensor | None = None, want_row_stats: bool = False):
+    """y = act(x @ w.T + bias) + resid.  x (M, K) bf16, w (N, K) bf16, bias f32 (N), resid (M, N) bf16|f32.
+    LayerNorm fold (pm_linear_bf16_ln): ln_stats (M, 2) + ln_s (N) normalise the input rows in the epilogue;
+    want_row_stats=True additionally returns the (M, N/64, 2) partial statistics of the output rows."""
     _cuda(x, w, bias, resid, out)
     _need(x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1], f"linear: x {tuple(x.shape)} vs w {tuple(w.shape)}")
     _need(x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16, "linear: x and w must be bf16")
@@ -68,6 +85,20 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none
     _need(out.shape == (M, N) and out.stride(1) == 1, "linear: bad out")
     if resid is not None:
         _need(resid.shape == (M, N) and resid.stride(1) == 1, "linear: resid must be (M, N), row-major")
+    if ln_stats is not None or want_row_stats:
+        _need((ln_stats is None) == (ln_s is None), "linear: ln_stats and ln_s go together")
+        if ln_stats is not None:
+            _need(ln_stats.shape == (M, 2) and ln_stats.dtype == torch.float32 and ln_stats.is_contiguous()
+                  and ln_s.dtype == torch.float32 and ln_s.numel() == N and ln_s.is_contiguous(), "linear: bad LayerNorm-fold operands")
+        rows = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device) if want_row_stats else None
+        rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16_ln(
+            x.data_ptr(), x.stride(0), 0, 0, w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
+            resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
+            _dt(resid) if resid is not None else 0, 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act],
+            ln_stats.data_ptr() if ln_stats is not None else None, ln_s.data_ptr() if ln_s is not None else None,
+            rows.data_ptr() if rows is not None else None, _stream()))
+        check(rc, f"pm_linear_bf16_ln(M={M}, N={N}, K={K})")
+        return (out, rows) if want_row_stats else out
     rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16(
         x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
         resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,

@@ -17,6 +17,8 @@ bfloat16 (``model.to(torch.bfloat16).cuda()``); anything the kernels do not cove
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor, nn
 
@@ -122,6 +124,12 @@ class MHA(nn.Module):
 
         return derived(self, "pack_" + names, params, build)
 
+    def _pack_ln(self, norm: "LayerNorm"):
+        """q/k/v projection with ``norm`` folded in: (w' = bf16(gamma (.) w), s[n] = sum_k w'[n][k],
+        c[n] = b[n] + sum_k beta[k] w[n][k]) so that proj(norm(x)) = rstd * (x w'^T - mean * s) + c."""
+        w, b = self._pack("qkv")
+        return derived(self, "pack_qkv_ln", (w, b, norm.weight, norm.bias), lambda: _fold_ln(w, b, norm))
+
     def forward(
         self,
         q: Tensor,
@@ -179,6 +187,16 @@ class MHA(nn.Module):
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
         y = ops.linear(o.view(-1, inner), self.out_proj.weight, _f32(self.out_proj, "b", self.out_proj.bias), resid=res2)
         return y.view(*lead, Lq, y.shape[-1])
+
+
+def _fold_ln(w: Tensor, b: Tensor | None, norm: "LayerNorm"):
+    wf = w.detach().float()
+    wl = (wf * norm.weight.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+    s = wl.float().sum(1).contiguous()
+    c = wf @ norm.bias.detach().float()
+    if b is not None:
+        c = c + b.float()
+    return wl, s, c.contiguous()
 
 
 class MLP(nn.Module):
@@ -278,6 +296,50 @@ class EncoderLayer(DecoderLayer):
     def forward(self, x: Tensor) -> Tensor:
         return DecoderLayer.forward(self, x, None)
 
+    # ---- LayerNorm folded into the GEMMs on either side of it (Encoder.forward drives this)
+    def chain_ok(self, x: Tensor) -> bool:
+        """True when this layer can run with both LayerNorms folded: plain pre-norm bf16 layer, shapes the
+        persistent GEMMs serve (pm_linear_ln_supported)."""
+        sa, mlp = self.sa, self.mlp
+        if not (self.pre_norm and type(sa).forward is MHA.forward and type(mlp).forward is MLP.forward and x.is_cuda
+                and x.dtype == torch.bfloat16 and sa.q_proj.weight.dtype == torch.bfloat16 and not self.training):
+            return False
+        M, d = x.numel() // x.shape[-1], x.shape[-1]
+        inner, hid = sa.n_heads * sa.head_dim, mlp.linear1.out_features
+        if sa.head_dim % 8 or sa.head_dim > 128 or mlp.act_name not in ("gelu",):
+            return False
+        return (ops.linear_ln_supported(M, d, inner, "none", True) and ops.linear_ln_supported(M, d, hid, "none", True)
+                and ops.linear_ln_supported(M, 3 * inner, d, "none", False)
+                and ops.linear_ln_supported(M, hid, d, mlp.act_name, False))
+
+    def forward_chain(self, x: Tensor, stats: Tensor | None, next_eps: float | None):
+        """x + sa(sa_norm(x)), then x + mlp(mlp_norm(x)) with the LayerNorms folded.  ``stats`` = (mean, rstd) of
+        the rows of ``x`` under sa_norm (None: run sa_norm as its own kernel); returns (x, stats of the output
+        rows under the next layer's sa_norm with ``next_eps``, or None)."""
+        sa, mlp = self.sa, self.mlp
+        lead, d = x.shape[:-1], x.shape[-1]
+        H, inner = sa.n_heads, sa.n_heads * sa.head_dim
+        x2 = x.reshape(-1, d)
+        if stats is None:
+            w, b = sa._pack("qkv")
+            qkv = ops.linear(self.sa_norm(x2), w, b)
+        else:
+            wl, s, c = sa._pack_ln(self.sa_norm)
+            qkv = ops.linear(x2, wl, c, ln_stats=stats, ln_s=s)
+        qkv = qkv.view(-1, x.shape[-2], 3 * inner)
+        o = ops.attention(qkv[..., :inner], qkv[..., inner : 2 * inner], qkv[..., 2 * inner :], H, False, None)
+        x2, rows = ops.linear(o.view(-1, inner), sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), resid=x2,
+                              want_row_stats=True)
+        st = ops.ln_stats_finalize(rows, d, self.mlp_norm.eps)
+        l1, l2 = mlp.linear1, mlp.linear2
+        wl, s, c = derived(mlp, "l1_ln", (l1.weight, l1.bias, self.mlp_norm.weight, self.mlp_norm.bias),
+                           lambda: _fold_ln(l1.weight, l1.bias, self.mlp_norm))
+        h = ops.linear(x2, wl, c, act=mlp.act_name, ln_stats=st, ln_s=s)
+        if next_eps is None:
+            return ops.linear(h, l2.weight, _f32(l2, "b", l2.bias), resid=x2).view(*lead, d), None
+        x2, rows = ops.linear(h, l2.weight, _f32(l2, "b", l2.bias), resid=x2, want_row_stats=True)
+        return x2.view(*lead, d), ops.ln_stats_finalize(rows, d, next_eps)
+
 
 class Encoder(nn.Sequential):
     def __init__(
@@ -297,6 +359,22 @@ class Encoder(nn.Sequential):
             EncoderLayer(d_model, n_heads, head_dim, bias, mlp_ratio, dropout, act, pre_norm, norm_eps)
             for _ in range(n_layers)
         ])
+
+    def forward(self, x: Tensor) -> Tensor:
+        """The layers in order.  Runs of plain pre-norm layers at GEMM-sized M are chained: each residual GEMM
+        (out_proj, linear2) also emits the row statistics of its output, and the next GEMM (q/k/v, linear1)
+        applies the LayerNorm in its epilogue - no LayerNorm kernel, no LN(x) round trip through HBM."""
+        layers = list(self)
+        fold = os.environ.get("PM_LN_FOLD", "1") != "0"
+        ok = [fold and isinstance(l, EncoderLayer) and type(l).forward is EncoderLayer.forward and l.chain_ok(x) for l in layers]
+        stats = None
+        for i, layer in enumerate(layers):
+            if not ok[i]:
+                x, stats = layer(x), None
+                continue
+            nxt = layers[i + 1].sa_norm.eps if i + 1 < len(layers) and ok[i + 1] else None
+            x, stats = layer.forward_chain(x, stats, nxt)
+        return x
 
 
 class Decoder(nn.ModuleList):

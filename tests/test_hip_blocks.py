@@ -75,6 +75,32 @@ def test_stacks(golden):
     assert rel(m(bfc(x), bfc(mem)), g["decoder2"]) < 3e-2
 
 
+def test_encoder_layernorm_fold_chain_matches_the_layerwise_path_and_the_oracle():
+    """At GEMM-sized M the Encoder chains its layers with the LayerNorms folded into the neighbouring GEMMs
+    (transformer.Encoder.forward); calling the layers one by one keeps the LayerNorm kernels.  Both must agree with
+    each other and with the fp32 oracle (first two sequences) to the block tolerance."""
+    from pytorch_models.transformer import Encoder
+
+    d, L, B = 128, 2048, 64  # M = 131072 rows: 512 tiles of 256 x 128 for the d-wide residual GEMMs
+    m, sd = prep(Encoder(3, d, n_heads=2, norm_eps=1e-6), 17)
+    x = synth_input("blk_chain", (B, L, d), 3)
+    xg = bfc(x)
+    assert all(l.chain_ok(xg) for l in m)
+    got = m(xg)
+    step = xg
+    for layer in m:
+        step = layer(step)
+    assert rel(got, step.cpu()) < 1e-2
+    assert not m[0].chain_ok(xg[:1])  # 2048 rows: below the persistent kernels' range
+    want = x[:2].to(torch.bfloat16).float()
+    for i in range(3):
+        want = RT.encoder_layer(sd, f"{i}.", 2, want, eps=1e-6)
+    assert rel(got[:2], want) < 2e-2
+    # batch rows are independent and position-independent: a permuted batch gives the permuted output, bit for bit
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).cuda()
+    torch.testing.assert_close(m(xg[perm]), got[perm], rtol=0, atol=0)
+
+
 def test_mha_call_forms_head_dim_64(golden):
     """transformer.py:36-45: k defaults to q, v to k; causal is top-left aligned; leading dims are free."""
     from pytorch_models.transformer import MHA

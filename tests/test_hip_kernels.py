@@ -139,6 +139,51 @@ def test_linear_linearity_at_full_size(ops):
     torch.testing.assert_close(y1[idx.cuda()].cpu(), want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(33000, 1024, 192, "none"), (33000, 1024, 192, "gelu"), (70000, 1032, 128, "gelu")])
+def test_linear_layernorm_fold_consumer(ops, M, N, K, act):
+    """pm_linear_bf16_ln as the consumer: LN(x) @ w.T + b computed as rstd * (x w'^T - mean * s) + c on the raw rows
+    (256x128 ring kernel and 256x256 wide kernel); the oracle normalises first, in fp32."""
+    assert ops.linear_ln_supported(M, N, K, act, False)
+    x = bf(synth_input("lf_x", (M, K), 70) * 2 + 0.5)
+    w = bf(synth_input("lf_w", (N, K), 71, scale=K ** -0.5))
+    b = synth_input("lf_b", (N,), 72, scale=0.1)
+    g = synth_input("lf_g", (K,), 73, scale=0.2) + 1
+    beta = synth_input("lf_beta", (K,), 74, scale=0.2)
+    eps = 1e-6
+    wl = bf(w.float() * g[None, :])
+    s, c = wl.float().sum(1), w.float() @ beta + b
+    xf = x.float()
+    mean, var = xf.mean(1), xf.var(1, unbiased=False)
+    stats = torch.stack([mean, (var + eps).rsqrt()], 1).contiguous()
+    got = ops.linear(x.cuda(), wl.cuda(), c.cuda(), act=act, ln_stats=stats.cuda(), ln_s=s.cuda())
+    idx = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M), torch.randint(0, M, (400,), generator=torch.Generator().manual_seed(2))])
+    want = RT.layernorm({"weight": g, "bias": beta}, "", xf[idx], eps) @ w.float().T + b
+    want = want if act == "none" else RT.activation(want, act)
+    close_bf16(got[idx.cuda()], want, rel=1.5e-2)  # one extra bf16 rounding (gamma (.) w) relative to the unfused path
+    assert torch.isfinite(got.float()).all()
+
+
+def test_linear_layernorm_fold_producer_row_statistics(ops):
+    """The residual GEMM's epilogue emits per-row (sum, sum of squares) of its bf16 outputs per 64-feature block;
+    pm_ln_stats_finalize reduces them to (mean, rstd).  The output itself must equal the plain kernel's bit for bit."""
+    M, N, K = 33000, 1024, 192
+    assert ops.linear_ln_supported(M, N, K, "none", True)
+    x = bf(synth_input("lp_x", (M, K), 75)).cuda()
+    w = bf(synth_input("lp_w", (N, K), 76, scale=K ** -0.5)).cuda()
+    b = synth_input("lp_b", (N,), 77, scale=0.1).cuda()
+    r = bf(synth_input("lp_r", (M, N), 78) + 0.3).cuda()
+    y, rows = ops.linear(x, w, b, resid=r, want_row_stats=True)
+    torch.testing.assert_close(y, ops.linear(x, w, b, resid=r), rtol=0, atol=0)
+    yb = y.float().view(M, N // 64, 64)
+    torch.testing.assert_close(rows[..., 0], yb.sum(-1), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(rows[..., 1], yb.square().sum(-1), rtol=1e-5, atol=1e-4)
+    stats = ops.ln_stats_finalize(rows, N, 1e-5)
+    yf = y.float()
+    torch.testing.assert_close(stats[:, 0], yf.mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats[:, 1], (yf.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+    assert not ops.linear_ln_supported(100, N, K, "none", True)  # small M: callers keep the LayerNorm kernel
+
+
 # ---------------------------------------------------------------- layernorm
 @pytest.mark.parametrize("M,d", [(5, 64), (197, 192), (1000, 768), (33, 1280), (7, 4096), (64, 8)])
 @pytest.mark.parametrize("eps", [1e-5, 1e-6])
