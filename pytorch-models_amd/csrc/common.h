@@ -42,8 +42,11 @@ struct PmLnFold {
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
 // async global -> LDS copy of 16 B per lane; the LDS destination is wave-uniform base + lane*16
+#ifndef PM_GLDS_AUX
+#define PM_GLDS_AUX 0  // cache-policy bits of the LDS-DMA loads: 1 = sc0, 2 = nt, 16 = sc1 (experiments; 0 in the product)
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
-  __builtin_amdgcn_global_load_lds((const PM_GLOBAL void*)gsrc, (PM_LDS void*)lds_dst_wave_base, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const PM_GLOBAL void*)gsrc, (PM_LDS void*)lds_dst_wave_base, 16, 0, PM_GLDS_AUX);
 }
 
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
