@@ -99,96 +99,105 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
   write_tile(smem);
   __syncthreads();
 
-  for (int t = 0; t < nT; ++t) {
-    const char* kbuf = smem + (t & 1) * 2 * TILE_B;
-    const char* vbuf = kbuf + TILE_B;
-    if (t + 1 < nT) load_tile(t + 1);
-
-    // work that cannot contribute is skipped per wave (the K/V staging and the barrier are not): a wave whose 32
-    // queries are all past Lq, a causal tile entirely above the wave's last query, and the second 32-key block of a
-    // tail tile when it holds no valid key (L = 197: 5 of the last tile's 64 keys exist)
-    const bool kb1 = t * KV_TILE + 32 < Lk;
-    const bool skip = !wave_live || (CAUSAL && t * KV_TILE > q0 + wave * 32 + 31);
-    if (!skip) {
-    // ---- S^T = K Q^T : two 32-key blocks
-    f32x16 sc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sc[kb][i] = kb == 1 && !kb1 ? -1e30f : 0.f;
-      if (kb == 1 && !kb1) continue;  // second 32-key block holds no valid key (tail tile): skip its MFMAs
-      const int row = kb * 32 + r;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *(const bf16x8*)(kbuf + row * 128 + swz_pos(row, 2 * s + hh) * 16);
-        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[kb], 0, 0, 0);
-      }
-    }
-
-    // ---- masks (key tail / causal), scale into the log2 domain
-    const int key_base = t * KV_TILE + 4 * hh;
-    const bool tail = (t + 1) * KV_TILE > Lk;
-    const bool diag = CAUSAL && ((t + 1) * KV_TILE - 1 > q0 + wave * 32);
-    float mx = -1e30f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (kb == 1 && !kb1) continue;
-        float v = sc[kb][i] * c;
-        if constexpr (BIAS) {  // additive attn_bias[b, h, q, k] (strides may be 0 = broadcast), natural-log units
-          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);
-          if (key < Lk) v = fmaf(bias_row[key], 1.4426950408889634f, v);
-        }
-        if (tail || diag) {
-          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);
-          if (key >= Lk || (CAUSAL && key > qi)) v = -1e30f;
-        }
-        sc[kb][i] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float ps = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (kb == 1 && !kb1) continue;
-        const float p = __builtin_amdgcn_exp2f(sc[kb][i] - m_new);
-        sc[kb][i] = p;
-        ps += p;
-      }
-    l_run = fmaf(l_run, alpha, ps);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-
-    // ---- O^T += V^T P^T
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (kb == 1 && !kb1) continue;
-        bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sc[kb][8 * s + j];
-        const int row = kb * 32 + 16 * s + 4 * (g >> 1) + qq;
-        const int flip = ((row >> 1) & 1) << 2;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int ch = db * 4 + 2 * (g & 1) + (pp >> 1);
-          const char* p0 = vbuf + row * 128 + ((ch ^ flip) * 16) + (pp & 1) * 8;
-          const bf16x8 vf = tr_read_pair(p0, p0 + 8 * 128);
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
-        }
-      }
-
-    }
-    if (t + 1 < nT) write_tile(smem + ((t + 1) & 1) * 2 * TILE_B);
-    __syncthreads();
+  // The tile body exists twice: tiles that need no mask at all (every key valid, below the causal diagonal for this
+  // wave, no bias) skip the per-score compare / select work - a third of the VALU instructions of a tile, and this
+  // kernel is VALU-bound (SQ counters at L = 1500: vector ALU active 79 % of the time, matrix pipe 31 %) - and only the
+  // trailing tiles run the masked form.  Both forms stage K/V and hit the barrier identically.
+#define PM_ATT_TILE(MASKED)                                                                                              \
+    const char* kbuf = smem + (t & 1) * 2 * TILE_B;                                                                      \
+    const char* vbuf = kbuf + TILE_B;                                                                                    \
+    if (t + 1 < nT) load_tile(t + 1);                                                                                    \
+    /* work that cannot contribute is skipped per wave (the K/V staging and the barrier are not): a wave whose 32 */     \
+    /* queries are all past Lq, a causal tile entirely above the wave's last query, and the second 32-key block of a */  \
+    /* tail tile when it holds no valid key (L = 197: 5 of the last tile's 64 keys exist) */                             \
+    const bool kb1 = !(MASKED) || t * KV_TILE + 32 < Lk;                                                                 \
+    const bool skip = !wave_live || (CAUSAL && t * KV_TILE > q0 + wave * 32 + 31);                                       \
+    if (!skip) {                                                                                                         \
+    /* ---- S^T = K Q^T : two 32-key blocks */                                                                           \
+    f32x16 sc[2];                                                                                                        \
+_Pragma("unroll")                                                                                                        \
+    for (int kb = 0; kb < 2; ++kb) {                                                                                     \
+_Pragma("unroll")                                                                                                        \
+      for (int i = 0; i < 16; ++i) sc[kb][i] = kb == 1 && !kb1 ? -1e30f : 0.f;                                           \
+      if (kb == 1 && !kb1) continue;  /* second 32-key block holds no valid key (tail tile): skip its MFMAs */           \
+      const int row = kb * 32 + r;                                                                                       \
+_Pragma("unroll")                                                                                                        \
+      for (int s = 0; s < 4; ++s) {                                                                                      \
+        const bf16x8 kf = *(const bf16x8*)(kbuf + row * 128 + swz_pos(row, 2 * s + hh) * 16);                            \
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[kb], 0, 0, 0);                                    \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    /* ---- masks (key tail / causal), scale into the log2 domain */                                                     \
+    const int key_base = t * KV_TILE + 4 * hh;                                                                           \
+    const bool tail = (t + 1) * KV_TILE > Lk;                                                                            \
+    const bool diag = CAUSAL && ((t + 1) * KV_TILE - 1 > q0 + wave * 32);                                                \
+    float mx = -1e30f;                                                                                                   \
+_Pragma("unroll")                                                                                                        \
+    for (int kb = 0; kb < 2; ++kb)                                                                                       \
+_Pragma("unroll")                                                                                                        \
+      for (int i = 0; i < 16; ++i) {                                                                                     \
+        if (kb == 1 && !kb1) continue;                                                                                   \
+        float v = sc[kb][i] * c;                                                                                         \
+        if constexpr (BIAS) {  /* additive attn_bias[b, h, q, k] (strides may be 0 = broadcast), natural-log units */    \
+          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);                                                   \
+          if (key < Lk) v = fmaf(bias_row[key], 1.4426950408889634f, v);                                                 \
+        }                                                                                                                \
+        if ((MASKED) && (tail || diag)) {                                                                                \
+          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);                                                   \
+          if (key >= Lk || (CAUSAL && key > qi)) v = -1e30f;                                                             \
+        }                                                                                                                \
+        sc[kb][i] = v;                                                                                                   \
+        mx = fmaxf(mx, v);                                                                                               \
+      }                                                                                                                  \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                              \
+    const float m_new = fmaxf(m_run, mx);                                                                                \
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                           \
+    m_run = m_new;                                                                                                       \
+    float ps = 0.f;                                                                                                      \
+_Pragma("unroll")                                                                                                        \
+    for (int kb = 0; kb < 2; ++kb)                                                                                       \
+_Pragma("unroll")                                                                                                        \
+      for (int i = 0; i < 16; ++i) {                                                                                     \
+        if (kb == 1 && !kb1) continue;                                                                                   \
+        const float p = __builtin_amdgcn_exp2f(sc[kb][i] - m_new);                                                       \
+        sc[kb][i] = p;                                                                                                   \
+        ps += p;                                                                                                         \
+      }                                                                                                                  \
+    l_run = fmaf(l_run, alpha, ps);                                                                                      \
+_Pragma("unroll")                                                                                                        \
+    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }                                           \
+    /* ---- O^T += V^T P^T */                                                                                            \
+_Pragma("unroll")                                                                                                        \
+    for (int kb = 0; kb < 2; ++kb)                                                                                       \
+_Pragma("unroll")                                                                                                        \
+      for (int s = 0; s < 2; ++s) {                                                                                      \
+        if (kb == 1 && !kb1) continue;                                                                                   \
+        bf16x8 pf;                                                                                                       \
+_Pragma("unroll")                                                                                                        \
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sc[kb][8 * s + j];                                                     \
+        const int row = kb * 32 + 16 * s + 4 * (g >> 1) + qq;                                                            \
+        const int flip = ((row >> 1) & 1) << 2;                                                                          \
+_Pragma("unroll")                                                                                                        \
+        for (int db = 0; db < 2; ++db) {                                                                                 \
+          const int ch = db * 4 + 2 * (g & 1) + (pp >> 1);                                                               \
+          const char* p0 = vbuf + row * 128 + ((ch ^ flip) * 16) + (pp & 1) * 8;                                         \
+          const bf16x8 vf = tr_read_pair(p0, p0 + 8 * 128);                                                              \
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);                                 \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    if (t + 1 < nT) write_tile(smem + ((t + 1) & 1) * 2 * TILE_B);                                                       \
+    __syncthreads();                                                                                                     \
+  /* end of PM_ATT_TILE */
+  int n_plain = BIAS ? 0 : (Lk / KV_TILE < nT ? Lk / KV_TILE : nT);  // leading tiles whose 64 keys all exist
+  if (CAUSAL) {  // ... and lie at or below this wave's FIRST query: (t + 1) * 64 - 1 <= q0 + wave * 32
+    const int below = (q0 + wave * 32 + 1) / KV_TILE;
+    n_plain = below < n_plain ? below : n_plain;
   }
+  int t = 0;
+  for (; t < n_plain; ++t) { PM_ATT_TILE(false) }
+  for (; t < nT; ++t) { PM_ATT_TILE(true) }
+#undef PM_ATT_TILE
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
