@@ -152,6 +152,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
     __builtin_amdgcn_s_barrier();  // every wave is done reading the ring buffer of this step: 4 KiB of it per wave
     char* stg = smem + cbuf * WSTAGE + wave * 4096;
     const int srow = lane >> 3, sch = lane & 7;
+    // row-wise side: this lane stores rows m0 + srow + 8 k (k = 0..7), 8 features at n0 + 64 hf + 8 sch.  One 64-bit
+    // multiply per tile; every other address is that base plus a wave-uniform offset (the per-store form cost ~10
+    // integer VALU instructions a store)
+    bf16* const ybase = Y + (int64_t)(m0 + srow) * ldy + n0 + sch * 8;
+    const bf16* const rbase = resid && !resid_period ? resid + (int64_t)(m0 + srow) * ldr + n0 + sch * 8 : nullptr;
+    const int mleft = M - m0 - srow;  // row k of this lane exists iff 8 k < mleft
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {  // 64-feature halves of the wave's 128 features
       f32x4 bvec[4], svec[4];
@@ -165,14 +171,20 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
       for (int i = 0; i < 4; ++i) {
         const float mu = lnst[i][0], rstd = lnst[i][1];  // (0, 1) without the LayerNorm fold
         bf16x8 rv[2];
-        if (resid) {  // coalesced 16-byte loads in the store layout; used after the staging round trip below
+        if (rbase) {  // coalesced 16-byte loads in the store layout; used after the staging round trip below
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const bool ok = i * 16 + p * 8 < mleft && n0 + hf * 64 + sch * 8 < N;
+            rv[p] = ok ? *(const bf16x8*)(rbase + (int64_t)(i * 16 + p * 8) * ldr + hf * 64) : bf16x8{};
+          }
+        } else if (resid) {  // periodic residual (row m reads row m % resid_period: a position table)
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             int mm = m0 + i * 16 + srow + p * 8;
             mm = mm < M ? mm : M - 1;
             int nn = n0 + hf * 64 + sch * 8;
             nn = nn < N ? nn : N - 8;
-            rv[p] = *(const bf16x8*)(resid + (int64_t)(resid_period ? mm % resid_period : mm) * ldr + nn);
+            rv[p] = *(const bf16x8*)(resid + (int64_t)(mm % resid_period) * ldr + nn);
           }
         }
 #pragma unroll
@@ -181,8 +193,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, acc[hf * 4 + jj][i][r] - mu * svec[jj][r], bvec[jj][r]);
           acc[hf * 4 + jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT, false>(v[r]);
+          v = apply_act4<ACT>(v);
           *(f32x4*)(stg + fr * 256 + (((4 * jj + fq) ^ fr) * 16)) = v;
         }
 #pragma unroll
@@ -198,8 +209,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o[r] = (bf16)lo[r]; o[4 + r] = (bf16)hi[r]; }
           }
-          const int mm = m0 + i * 16 + row, nn = n0 + hf * 64 + sch * 8;
-          if (mm < M && nn < N) *(bf16x8*)(Y + (int64_t)mm * ldy + nn) = o;  // N % 8 == 0 on this path
+          if (i * 16 + p * 8 < mleft && n0 + hf * 64 + sch * 8 < N)  // N % 8 == 0 on this path
+            *(bf16x8*)(ybase + (int64_t)(i * 16 + p * 8) * ldy + hf * 64) = o;
         }
       }
     }
