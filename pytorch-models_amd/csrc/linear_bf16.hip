@@ -324,12 +324,21 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s) {
+        if (s == 0 && kt == 0) {  // a tile's first MFMAs start from the constant 0: no accumulator clearing anywhere
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][j], b[s][i], acc[j][i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][j], b[s][i], zero, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][j], b[s][i], acc[j][i], 0, 0, 0);
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
     }
     const int cbuf = buf;
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[j][i])); acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[j][i]));
       ++ti;
       continue;
     }
@@ -359,6 +368,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
       __builtin_amdgcn_s_barrier();
       char* stg = smem + cbuf * STAGE_BYTES + wave * 4096;
       const int srow = lane >> 3, sch = lane & 7;  // row-wise side: 8 lanes x 8 features per 64-feature row segment
+      // one 64-bit multiply per tile: this lane's rows are m0 + srow + 8 k, every other address a uniform offset from it
+      bf16* const ybase = (bf16*)Y + (int64_t)(m0 + srow) * ldy + n0 + sch * 8;
+      float* const sbase = ln.row_out ? ln.row_out + ((int64_t)(m0 + srow) * (N >> 6) + (n0 >> 6)) * 2 : nullptr;
+      const int mleft = M - m0 - srow;  // row k of this lane exists iff 8 k < mleft
+      const bool n_ok = n0 + sch * 8 < N;
       f32x4 bvec[4], svec[4];  // this lane's bias (and LN-fold column sum) values, loaded once per tile
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -374,7 +388,6 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, acc[j][i][r] - mu * svec[j][r], bvec[j][r]);
-          acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT, false>(v[r]);
           // staging row fr (64 f32 = 256 B), 16-byte chunk c = 4j + fq stored at position c ^ fr
@@ -393,20 +406,19 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o[r] = (bf16)lo[r]; o[4 + r] = (bf16)hi[r]; }
           }
-          const int mm = m0 + i * 16 + row, nn = n0 + sch * 8;
+          const bool ok = i * 16 + p * 8 < mleft && n_ok;
           if (ln.row_out) {  // (sum, sum of squares) of this row's 64 ROUNDED outputs: the next LayerNorm's partials
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) { const float f = (float)o[r]; s1 += f; s2 = fmaf(f, f, s2); }
             s1 = sum8_dpp(s1);  // the row's 8 lanes (sch 0..7): DPP adds, no LDS traffic
             s2 = sum8_dpp(s2);
-            if (sch == 0 && mm < M && nn < N)
-              *(f32x2*)(ln.row_out + ((int64_t)mm * (N >> 6) + (n0 >> 6)) * 2) = f32x2{s1, s2};
+            if (sch == 0 && ok) *(f32x2*)(sbase + (int64_t)(i * 16 + p * 8) * (N >> 6) * 2) = f32x2{s1, s2};
           }
 #ifdef PM_ABLATE_STORES  // experiment only
           asm volatile("" ::"v"(o));
 #else
-          if (mm < M && nn < N) *(bf16x8*)((bf16*)Y + (int64_t)mm * ldy + nn) = o;  // N % 8 == 0 on this path
+          if (ok) *(bf16x8*)(ybase + (int64_t)(i * 16 + p * 8) * ldy) = o;  // N % 8 == 0 on this path
 #endif
         }
       }
@@ -418,7 +430,6 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
         for (int i = 0; i < 4; ++i) {
           const int m = m0 + i * 16 + fr;
           f32x4 v = acc[j][i];
-          acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (n >= N || m >= M) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

@@ -133,10 +133,18 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
       for (int j = 0; j < 8; ++j) a[j] = wread(wcur, wn * 128 + j * 16 + fr, fq);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      if (kt == 0) {  // a tile's first step starts from the constant 0: nobody has to clear 128 accumulator registers
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], zero, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
     }
     const int cbuf = buf;
@@ -192,7 +200,6 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
           f32x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, acc[hf * 4 + jj][i][r] - mu * svec[jj][r], bvec[jj][r]);
-          acc[hf * 4 + jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
           v = apply_act4<ACT>(v);
           *(f32x4*)(stg + fr * 256 + (((4 * jj + fq) ^ fr) * 16)) = v;
         }
