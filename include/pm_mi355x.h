@@ -197,6 +197,14 @@ int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_t
 /* ++*pos_ptr, as its own launch (every workgroup of the step has read t by then). */
 int pm_dec_advance(int32_t* pos_ptr, void* stream);
 
+/* pm_dec_argmax_reduce + the NEXT step's pm_dec_embed + pm_dec_advance in one launch (two launches fewer per decode
+ * step): sequence b's workgroup picks its token as pm_dec_argmax_reduce does, writes x[b] = emb[token] + pos[t + 1], and
+ * the last workgroup to finish - an agent-scope ticket in *ticket (int32, zero before the first launch, zero again after
+ * every launch) - stores t + 1 to *pos_ptr.  Before a run's first step: *pos_ptr = 0, tok_cur set, pm_dec_embed once. */
+int pm_dec_next_token(const float* ws_val, const int32_t* ws_idx, int64_t n_tiles, int32_t* pos_ptr, const int64_t* prompt,
+                      int64_t P, int64_t* tok_cur, int64_t* tokens_out, int64_t Ttot, float* margin_out, const void* emb,
+                      const float* pos, float* x, int64_t d, int64_t V, int32_t* ticket, int64_t B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

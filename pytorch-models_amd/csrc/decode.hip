@@ -601,10 +601,16 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
                                                                 int nwg, const int* __restrict__ pos_ptr,
                                                                 const int64_t* __restrict__ prompt, int P,
                                                                 int64_t* __restrict__ tok_cur, int64_t* __restrict__ tokens_out,
-                                                                int Ttot, float* __restrict__ margin_out) {
+                                                                int Ttot, float* __restrict__ margin_out,
+                                                                // fused tail (all null / 0 for the plain reduce):
+                                                                const bf16* __restrict__ E, const float* __restrict__ pos_tab,
+                                                                float* __restrict__ x, int d, int V, int* ticket,
+                                                                int* pos_rw) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ float s2[4];
+  __shared__ int64_t snext;
+  __shared__ int st;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float bv = -INFINITY, second = -INFINITY;
   int bi = 0x7fffffff;
@@ -636,6 +642,32 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
     // NOTE: `second` is the runner-up among per-tile winners, i.e. a lower bound on the true top1 - top2 margin's
     // complement; it is diagnostic only (tests classify near-ties with it).
     if (margin_out && t + 1 < Ttot) margin_out[(int64_t)b * Ttot + t + 1] = bv - second;
+    snext = next;
+    st = t;
+  }
+  if (!E) return;
+  // ---- fused tail: the next step's input row x[b] = E[next] + pos[t + 1] (what dec_embed would compute after the
+  // position moved), then the LAST workgroup to get here moves the position: every workgroup read it before its ticket
+  __syncthreads();
+  const int t1 = st + 1;
+  int64_t id = snext;
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  for (int c = tid; c < d / 8; c += 256) {
+    const bf16x8 e = *(const bf16x8*)(E + id * d + c * 8);
+    const f32x4 p0 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8), p1 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8 + 4);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o0[i] = (float)e[i] + p0[i]; o1[i] = (float)e[4 + i] + p1[i]; }
+    *(f32x4*)(x + (int64_t)b * d + c * 8) = o0;
+    *(f32x4*)(x + (int64_t)b * d + c * 8 + 4) = o1;
+  }
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int n = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == (int)gridDim.x - 1) {
+      __hip_atomic_store(pos_rw, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -795,7 +827,28 @@ extern "C" int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, 
     return PM_EINVAL;
   hipLaunchKernelGGL(dec_argmax_reduce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, ws_val,
                      (const int*)ws_idx, (int)n_tiles, (const int*)pos_ptr, prompt, (int)P, tok_cur, tokens_out, (int)Ttot,
-                     margin_out);
+                     margin_out, (const bf16*)nullptr, (const float*)nullptr, (float*)nullptr, 0, 0, (int*)nullptr,
+                     (int*)nullptr);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+/* pm_dec_argmax_reduce + the next step's pm_dec_embed + pm_dec_advance in ONE launch: each sequence's workgroup picks
+ * its token, writes x[b] = emb[token] + pos[t + 1], and the last workgroup to finish (agent-scope ticket, left at 0)
+ * stores t + 1 to *pos_ptr.  Before the first step of a run the caller sets *pos_ptr = 0, tok_cur and runs
+ * pm_dec_embed once. */
+extern "C" int pm_dec_next_token(const float* ws_val, const int32_t* ws_idx, int64_t n_tiles, int32_t* pos_ptr,
+                                 const int64_t* prompt, int64_t P, int64_t* tok_cur, int64_t* tokens_out, int64_t Ttot,
+                                 float* margin_out, const void* emb, const float* pos, float* x, int64_t d, int64_t V,
+                                 int32_t* ticket, int64_t B, void* stream) {
+  if (!ws_val || !ws_idx || !pos_ptr || !prompt || !tok_cur || !tokens_out || n_tiles <= 0 || P <= 0 || B <= 0 || Ttot < P)
+    return PM_EINVAL;
+  if (!emb || !pos || !x || !ticket || d <= 0 || V <= 0) return PM_EINVAL;
+  if (d % 8) return PM_EUNSUPPORTED;
+  if (((uintptr_t)emb | (uintptr_t)pos | (uintptr_t)x) & 15) return PM_EALIGN;
+  hipLaunchKernelGGL(dec_argmax_reduce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, ws_val,
+                     (const int*)ws_idx, (int)n_tiles, (const int*)pos_ptr, prompt, (int)P, tok_cur, tokens_out, (int)Ttot,
+                     margin_out, (const bf16*)emb, pos, x, (int)d, (int)V, (int*)ticket, (int*)pos_ptr);
   PM_CHECK_LAUNCH();
   return PM_OK;
 }

@@ -80,8 +80,10 @@ class GreedyDecoder:
                 (out.stride(0) if out is not None else 0) if ldo is None else ldo, B, N, K, act, mode, _ptr(kc), _ptr(vc),
                 inner, H, Tmax, self.pos.data_ptr(), self.ws_val.data_ptr(), self.ws_idx.data_ptr(), None)
 
-        add(L.pm_dec_embed, self.tok_cur.data_ptr(), E.data_ptr(), pos_f32.data_ptr(), self.pos.data_ptr(), self.x.data_ptr(),
-            B, d, V, None)
+        # x for position 0 comes from reset(); every later x row is written by the previous step's pm_dec_next_token
+        self._embed0 = (L.pm_dec_embed, (self.tok_cur.data_ptr(), E.data_ptr(), pos_f32.data_ptr(), self.pos.data_ptr(),
+                                         self.x.data_ptr(), B, d, V, None))
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.self_k, self.self_v, self.cross_kv, self._cross_w = [], [], [], []
         for layer in dec.layers:
             if not layer.pre_norm or layer.ca is None:
@@ -133,9 +135,10 @@ class GreedyDecoder:
                        self.x, self.x, d)
         g, b = _f32(dec.norm, "g", dec.norm.weight), _f32(dec.norm, "b", dec.norm.bias)
         dec_linear(self.x, d, g, b, dec.norm.eps, E, None, None, None, V, mode=2, ldo=0)
-        add(L.pm_dec_argmax_reduce, self.ws_val.data_ptr(), self.ws_idx.data_ptr(), n_tiles, self.pos.data_ptr(),
-            self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot, _ptr(self.margins), B, None)
-        add(L.pm_dec_advance, self.pos.data_ptr(), None)
+        # token choice + the next step's embedding row + position advance: one launch
+        add(L.pm_dec_next_token, self.ws_val.data_ptr(), self.ws_idx.data_ptr(), n_tiles, self.pos.data_ptr(),
+            self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot, _ptr(self.margins),
+            E.data_ptr(), pos_f32.data_ptr(), self.x.data_ptr(), d, V, self.ticket.data_ptr(), B, None)
 
     def rebind(self, memory: Tensor, prompt: Tensor) -> None:
         """New clips, same geometry: re-project the cross K/V INTO the existing buffers and swap the prompt, so the
@@ -164,7 +167,10 @@ class GreedyDecoder:
 
     def reset(self) -> None:
         self.pos.zero_()
+        self.ticket.zero_()
         self.tok_cur.copy_(self.prompt[:, 0])
+        fn, args = self._embed0  # x[b] = emb[prompt[b, 0]] + pos[0]
+        check(fn(*args[:-1], torch.cuda.current_stream().cuda_stream), "pm_dec_embed")
 
     def run(self, graph: bool = True) -> Tensor:
         if not graph:
