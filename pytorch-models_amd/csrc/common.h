@@ -49,6 +49,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
   __builtin_amdgcn_global_load_lds((const PM_GLOBAL void*)gsrc, (PM_LDS void*)lds_dst_wave_base, 16, 0, PM_GLDS_AUX);
 }
 
+// 16-byte global store / load with sc1 (L1 bypassed, agent-coherent): the payload side of a workgroup-to-workgroup
+// hand-off that uses an agent-scope ticket instead of cache-wide fences (MI355X_MICROARCH.md, inter-workgroup visibility).
+// The load returns after its own s_waitcnt vmcnt(0) - the compiler does not track asm loads.
+__device__ __forceinline__ void store_sc1_x4(f32x4* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 load_sc1_x4(const f32x4* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one rcp, one exp, five fma.

@@ -63,6 +63,11 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   const int n0 = blockIdx.x * (DL_FEATS * FT);
   const int fi = lane & 15, kq = lane >> 4;
   const int ksteps = K >> 5;
+  // K may be split over gridDim.y workgroups (plain mode, no LayerNorm): part kp takes K steps [ks0, ks1) - every
+  // workgroup then reads 1 / gridDim.y of the activations instead of all of them (fc2: 256 KB per workgroup through one
+  // CU's L2 path was the kernel's time) - and the parts are combined by the last one to finish (below)
+  const int kparts = gridDim.y, kp = blockIdx.y;
+  const int ks0 = ksteps * kp / kparts, ks1 = ksteps * (kp + 1) / kparts;
 
   f32x4 acc[FT][MT];
 #pragma unroll
@@ -86,13 +91,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
 
   // LN kernels: exactly ONE trip for every wave (host guarantees ksteps <= 4*NSTEP), even a wave that owns no K step:
   // the trip contains workgroup barriers
-  for (int sb = wave, trip = 0; LN ? trip < 1 : sb < ksteps; sb += 4 * NSTEP, ++trip) {
+  for (int sb = ks0 + wave, trip = 0; LN ? trip < 1 : sb < ks1; sb += 4 * NSTEP, ++trip) {
     bf16x8 a[NSTEP][FT];
     f32x4 xv[NSTEP][MT][2];
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u) {
       int s = sb + 4 * u;
-      s = s < ksteps ? s : ksteps - 1;
+      s = s < ks1 ? s : ks1 - 1;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         xv[u][t][0] = *(const f32x4*)(xrow[t] + s * 32);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         float sm = 0.f;
 #pragma unroll
         for (int u = 0; u < NSTEP; ++u)
-          if (sb + 4 * u < ksteps) {
+          if (sb + 4 * u < ks1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) sm += xv[u][t][0][i] + xv[u][t][1][i];
           }
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         float q = 0.f;
 #pragma unroll
         for (int u = 0; u < NSTEP; ++u)
-          if (sb + 4 * u < ksteps) {
+          if (sb + 4 * u < ks1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float d0 = xv[u][t][0][i] - mean[t], d1 = xv[u][t][1][i] - mean[t];
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u) {
-      if (sb + 4 * u >= ksteps) break;
+      if (sb + 4 * u >= ks1) break;
       const int k0 = (sb + 4 * u) * 32 + kq * 8;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -186,14 +191,49 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   int best_i[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) { best_v[t] = -INFINITY; best_i[t] = 0x7fffffff; }
+  f32x4 vs[FT][MT];
 #pragma unroll
-  for (int f = 0; f < FT; ++f) {
-    const int n = n0 + f * 16 + kq * 4;
+  for (int f = 0; f < FT; ++f)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       f32x4 v = *(const f32x4*)(red + (((0 * FT + f) * MT + t) * 64 + lane) * 4);
 #pragma unroll
       for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + (((w * FT + f) * MT + t) * 64 + lane) * 4);
+      vs[f][t] = v;
+    }
+  if (kparts > 1) {
+    // K split: publish this part's tile (sc1 stores), take a ticket, and only the last part to finish goes on: it adds
+    // the parts in part order (deterministic) and runs the epilogue.  Hand-off as in MI355X_MICROARCH.md (first row of
+    // the measured table): every byte stored and loaded with sc1, vmcnt(0) before the agent-scope add, the adding wave
+    // is the only reader.  ws_val = (tiles * parts * FT * MT * 64) float4 partials, ws_idx = one int32 ticket per tile.
+    f32x4* my = (f32x4*)ws_val + ((int64_t)(blockIdx.x * kparts + kp) * FT * MT) * 64 + lane;
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) store_sc1_x4(my + (f * MT + t) * 64, vs[f][t]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(ws_idx + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != kparts - 1) return;
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < kparts; ++q) {
+          v += load_sc1_x4((const f32x4*)ws_val + ((int64_t)(blockIdx.x * kparts + q) * FT * MT + f * MT + t) * 64 + lane);
+        }
+        vs[f][t] = v;
+      }
+    if (lane == 0) __hip_atomic_store(ws_idx + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int f = 0; f < FT; ++f) {
+    const int n = n0 + f * 16 + kq * 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const f32x4 v = vs[f][t];
       const int row = t * 16 + fi;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -765,6 +805,59 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
     rc = dl_launch<PM_ACT_NONE, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                            (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
+  if (rc != PM_OK) return rc;
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+/* pm_dec_linear in plain mode (no LayerNorm) with K split over k_split (2..8) workgroups per 16-feature tile: each part
+ * reads 1 / k_split of x and of its weight rows; the last part to finish (agent-scope ticket, no spinning) adds the parts
+ * in part order and applies bias / activation / residual.  split_ws: ceil(N / 16) * k_split * mt * 256 floats (mt = ceil(M / 16) rounded up to 1, 2 or 4);
+ * split_cnt: ceil(N / 16) int32, zero before the first launch and zero again after every launch. */
+extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                                    const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
+                                    int act, int64_t k_split, float* split_ws, int32_t* split_cnt, void* stream) {
+  if (!x || !w || !out || !split_ws || !split_cnt || M <= 0 || N <= 0 || K <= 0) return PM_EINVAL;
+  if (M > 64 || K % 32) return PM_EUNSUPPORTED;
+  if (k_split < 2 || k_split > 8 || K / 32 < k_split) return PM_EINVAL;
+  if (ldx < K || ldw < K || ldx % 4 || ldw % 8) return PM_EALIGN;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)split_ws) & 15) return PM_EALIGN;
+  if (ldo < N || (resid && ldr < N)) return PM_EINVAL;
+  if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
+  const int nwg = (int)((N + DL_FEATS - 1) / DL_FEATS);
+  const int mt = (int)((M + 15) / 16);
+  const int k_eff = (int)(((K / 32 + k_split - 1) / k_split) * 32);  // the longest part decides the instantiation
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(nwg, (unsigned)k_split);
+  int rc;
+  // (dl_launch picks NSTEP from its K argument; the kernel takes the true K from its own parameter list, so pass
+  // k_eff only for that choice: both instantiations below receive the real K)
+  const int per_wave = (k_eff / 32 + 3) / 4;
+#define PM_DLK(ACT_, NS_)                                                                                             \
+  do {                                                                                                                \
+    if (mt <= 1) hipLaunchKernelGGL((dec_linear_kernel<ACT_, 1, 1, NS_, false>), grid, dim3(256), 0, st, x, (int)ldx,   \
+                                    (const float*)nullptr, (const float*)nullptr, 0.f, (const bf16*)w, ldw, bias, resid, \
+                                    (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, DL_PLAIN, (bf16*)nullptr,           \
+                                    (bf16*)nullptr, 0, 0, 0, (const int*)nullptr, split_ws, (int*)split_cnt, nwg);       \
+    else if (mt == 2) hipLaunchKernelGGL((dec_linear_kernel<ACT_, 2, 1, NS_, false>), grid, dim3(256), 0, st, x,         \
+                                         (int)ldx, (const float*)nullptr, (const float*)nullptr, 0.f, (const bf16*)w,    \
+                                         ldw, bias, resid, (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, DL_PLAIN,     \
+                                         (bf16*)nullptr, (bf16*)nullptr, 0, 0, 0, (const int*)nullptr, split_ws,          \
+                                         (int*)split_cnt, nwg);                                                          \
+    else hipLaunchKernelGGL((dec_linear_kernel<ACT_, 4, 1, 4, false>), grid, dim3(256), 0, st, x, (int)ldx,              \
+                            (const float*)nullptr, (const float*)nullptr, 0.f, (const bf16*)w, ldw, bias, resid,         \
+                            (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, DL_PLAIN, (bf16*)nullptr, (bf16*)nullptr, 0, \
+                            0, 0, (const int*)nullptr, split_ws, (int*)split_cnt, nwg);                                   \
+  } while (0)
+  rc = PM_OK;
+  if (act == PM_ACT_GELU) {
+    if (per_wave <= 4 || mt > 2) PM_DLK(PM_ACT_GELU, 4);
+    else PM_DLK(PM_ACT_GELU, 8);
+  } else {
+    if (per_wave <= 4 || mt > 2) PM_DLK(PM_ACT_NONE, 4);
+    else PM_DLK(PM_ACT_NONE, 8);
+  }
+#undef PM_DLK
   if (rc != PM_OK) return rc;
   PM_CHECK_LAUNCH();
   return PM_OK;

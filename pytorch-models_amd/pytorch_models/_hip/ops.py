@@ -319,6 +319,26 @@ def dec_linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, ln: tuple | 
     return out
 
 
+def dec_linear_ksplit(x: Tensor, w: Tensor, bias: Tensor | None = None, *, k_split: int, act: str = "none",
+                      resid: Tensor | None = None) -> Tensor:
+    """dec_linear without LayerNorm, K split over k_split workgroups per 16-feature tile (pm_dec_linear_ksplit)."""
+    _cuda(x, w, bias, resid)
+    _need(x.dtype == torch.float32 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2, "dec_linear_ksplit: f32 x, bf16 w")
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    nt, mt = (N + 15) // 16, (M + 15) // 16
+    mt = 1 if mt <= 1 else 2 if mt == 2 else 4  # row tiles of the kernel instantiation
+    ws = torch.empty(nt * k_split * mt * 256, dtype=torch.float32, device=x.device)
+    cnt = torch.zeros(nt, dtype=torch.int32, device=x.device)
+    rc = lib().pm_dec_linear_ksplit(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
+                                    resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
+                                    out.data_ptr(), out.stride(0), M, N, K, ACT[act], k_split, ws.data_ptr(), cnt.data_ptr(), _stream())
+    check(rc, f"pm_dec_linear_ksplit(M={M}, N={N}, K={K}, k_split={k_split})")
+    _need(int(cnt.abs().sum()) == 0, "pm_dec_linear_ksplit left a ticket counter non-zero")
+    return out
+
+
 def dec_argmax(x: Tensor, w: Tensor, ln: tuple) -> tuple[Tensor, Tensor]:
     """Per-row argmax (and max) of LN(x) @ w.T without materialising the logits."""
     M, K = x.shape

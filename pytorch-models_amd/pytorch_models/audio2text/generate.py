@@ -10,6 +10,8 @@ step is captured ONCE into a HIP graph and replayed - no tracing compiler, no ho
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -73,7 +75,26 @@ class GreedyDecoder:
         def add(fn, *args):
             self.launches.append((fn, args))
 
+        # plain projections with a long K (fc2: K = 4 d) are split over workgroups along K: see pm_dec_linear_ksplit
+        ks_min = int(os.environ.get("PM_DEC_KSPLIT_MINK", "1024"))
+        self._ks_bufs = []
+
+        def dec_linear_ks(x, K, w, bias, resid, out, N, act=0):
+            ksp = int(os.environ.get("PM_DEC_KSPLIT", "4"))
+            ksp = max(2, min(ksp, 8, K // 32))
+            nt, mt = (N + 15) // 16, (B + 15) // 16
+            mt = 1 if mt <= 1 else 2 if mt == 2 else 4  # row tiles of the kernel instantiation
+            ws = torch.empty(nt * ksp * mt * 256, **f32)
+            cnt = torch.zeros(nt, dtype=torch.int32, device=dev)
+            self._ks_bufs += [ws, cnt]
+            self._keep += [w, bias]
+            add(L.pm_dec_linear_ksplit, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _ptr(bias), _ptr(resid),
+                resid.stride(0) if resid is not None else 0, out.data_ptr(), out.stride(0), B, N, K, act, ksp,
+                ws.data_ptr(), cnt.data_ptr(), None)
+
         def dec_linear(x, K, gamma, beta, eps, w, bias, resid, out, N, act=0, mode=0, kc=None, vc=None, ldo=None):
+            if mode == 0 and gamma is None and K >= ks_min and int(os.environ.get("PM_DEC_KSPLIT", "4")) > 1:
+                return dec_linear_ks(x, K, w, bias, resid, out, N, act)
             self._keep += [w, bias, gamma, beta]
             add(L.pm_dec_linear, x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), w.data_ptr(), w.stride(0),
                 _ptr(bias), _ptr(resid), resid.stride(0) if resid is not None else 0, _ptr(out),

@@ -53,6 +53,22 @@ def test_dec_linear_fp32_exact(ops, M, N, K):
     torch.testing.assert_close(got.cpu().double(), xn @ w.double().T, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(32, 512, 2048, 4), (32, 512, 2048, 8), (2, 384, 1536, 2), (33, 64, 2048, 3), (64, 100, 512, 4), (1, 16, 64, 2)])
+def test_dec_linear_k_split_over_workgroups(ops, M, N, K, ks):
+    """pm_dec_linear_ksplit: K split over ks workgroups per 16-feature tile, combined by the last one to finish; fp32-exact
+    like pm_dec_linear, ticket counters back at zero (checked inside ops.dec_linear_ksplit), a relaunch gives the same bits."""
+    x = synth_input("dk_x", (M, K), 81) * 2
+    w = bf(synth_input("dk_w", (N, K), 82, scale=K ** -0.5))
+    b = synth_input("dk_b", (N,), 83, scale=0.1)
+    r = synth_input("dk_r", (M, N), 84)
+    want = x.double() @ w.double().T + b.double()
+    got = ops.dec_linear_ksplit(x.cuda(), w.cuda(), b.cuda(), k_split=ks)
+    torch.testing.assert_close(got.cpu().double(), want, rtol=2e-6, atol=2e-6)
+    got2 = ops.dec_linear_ksplit(x.cuda(), w.cuda(), b.cuda(), k_split=ks, act="gelu", resid=r.cuda())
+    torch.testing.assert_close(got2.cpu(), (RT.activation(want, "gelu") + r.double()).float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.dec_linear_ksplit(x.cuda(), w.cuda(), b.cuda(), k_split=ks), got, rtol=0, atol=0)
+
+
 def test_dec_argmax_matches_torch_argmax_including_ties(ops):
     M, N, K = 32, 51865, 512
     x = synth_input("da_x", (M, K), 7)
