@@ -181,8 +181,8 @@ int pm_dec_attention(const float* q, const void* kc, const void* vc, int64_t str
  * part reads 1 / k_split of x (at M = 32, K = 2048 every workgroup of the unsplit kernel pulls all 256 KB of x through
  * one CU's L2 path) and of its weight rows; the last part to finish - an agent-scope ticket, no spinning - adds the
  * parts in part order (deterministic) and applies bias / activation / residual.  split_ws: ceil(N / 16) * k_split *
- * mt * 256 floats with mt = ceil(M / 16) rounded up to 1, 2 or 4, 16-byte aligned; split_cnt: ceil(N / 16) int32, zero before the first launch, zero again
- * after every launch (graph replay).  K / 32 >= k_split. */
+ * mt * 256 floats with mt = ceil(M / 16) rounded up to 1, 2 or 4, 16-byte aligned; split_cnt: ceil(N / 16) * 4 int32 (one ticket per feature tile and
+ * row tile), zero before the first launch, zero again after every launch (graph replay).  K / 32 >= k_split. */
 int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const float* resid,
                          int64_t ldr, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K, int act, int64_t k_split,
                          float* split_ws, int32_t* split_cnt, void* stream);

@@ -19,6 +19,8 @@
 //                     the prompt, appends to the output.
 //  dec_advance        ++t (its own launch: every workgroup of the step has read t by then).
 // The position t and the current tokens live in device memory, so ONE captured hipGraph replays every step.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   const int n0 = blockIdx.x * (DL_FEATS * FT);
   const int fi = lane & 15, kq = lane >> 4;
   const int ksteps = K >> 5;
+  const int rbase = blockIdx.z * (16 * MT);  // row tiles may be spread over gridDim.z workgroups (independent rows)
   // K may be split over gridDim.y workgroups (plain mode, no LayerNorm): part kp takes K steps [ks0, ks1) - every
   // workgroup then reads 1 / gridDim.y of the activations instead of all of them (fc2: 256 KB per workgroup through one
   // CU's L2 path was the kernel's time) - and the parts are combined by the last one to finish (below)
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   const float* xrow[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    int row = t * 16 + fi;
+    int row = rbase + t * 16 + fi;
     row = row < M ? row : M - 1;
     xrow[t] = x + (int64_t)row * ldx + kq * 8;
   }
@@ -206,14 +209,15 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
     // the parts in part order (deterministic) and runs the epilogue.  Hand-off as in MI355X_MICROARCH.md (first row of
     // the measured table): every byte stored and loaded with sc1, vmcnt(0) before the agent-scope add, the adding wave
     // is the only reader.  ws_val = (tiles * parts * FT * MT * 64) float4 partials, ws_idx = one int32 ticket per tile.
-    f32x4* my = (f32x4*)ws_val + ((int64_t)(blockIdx.x * kparts + kp) * FT * MT) * 64 + lane;
+    const int tile_id = blockIdx.x + gridDim.x * blockIdx.z;
+    f32x4* my = (f32x4*)ws_val + ((int64_t)(tile_id * kparts + kp) * FT * MT) * 64 + lane;
 #pragma unroll
     for (int f = 0; f < FT; ++f)
 #pragma unroll
       for (int t = 0; t < MT; ++t) store_sc1_x4(my + (f * MT + t) * 64, vs[f][t]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(ws_idx + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) ticket = __hip_atomic_fetch_add(ws_idx + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != kparts - 1) return;
 #pragma unroll
@@ -222,11 +226,11 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
       for (int t = 0; t < MT; ++t) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int q = 0; q < kparts; ++q) {
-          v += load_sc1_x4((const f32x4*)ws_val + ((int64_t)(blockIdx.x * kparts + q) * FT * MT + f * MT + t) * 64 + lane);
+          v += load_sc1_x4((const f32x4*)ws_val + ((int64_t)(tile_id * kparts + q) * FT * MT + f * MT + t) * 64 + lane);
         }
         vs[f][t] = v;
       }
-    if (lane == 0) __hip_atomic_store(ws_idx + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(ws_idx + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #pragma unroll
   for (int f = 0; f < FT; ++f) {
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const f32x4 v = vs[f][t];
-      const int row = t * 16 + fi;
+      const int row = rbase + t * 16 + fi;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int nn = n + r;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         const int oi = __shfl_xor(bi, o, 64);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       }
-      const int row = t * 16 + fi;
+      const int row = rbase + t * 16 + fi;
       if (kq == 0 && row < M) {
         ws_val[(int64_t)row * nwg + blockIdx.x] = bv;
         ws_idx[(int64_t)row * nwg + blockIdx.x] = bi;
@@ -786,9 +790,14 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
   const int per_wave = (int)((K / 32 + 3) / 4);
   const int ft = mode == DL_ARGMAX ? (gamma && per_wave > 4 ? 2 : 4) : 1;  // see pm_dec_argmax_tile()
   const int nwg = (int)((N + DL_FEATS * ft - 1) / (DL_FEATS * ft));
-  const int mt = (int)((M + 15) / 16);
+  int mt = (int)((M + 15) / 16);
   hipStream_t st = (hipStream_t)stream;
   int rc = PM_OK;
+  // rows are independent: with few feature tiles (N / 16 workgroups) the 16-row tiles go to separate workgroups, each
+  // reading only its rows of x (PM_DEC_ROWSPLIT=0 switches this off)
+  static const bool rowsplit = [] { const char* e = getenv("PM_DEC_ROWSPLIT"); return !e || atoi(e) != 0; }();
+  unsigned gz = 1;
+  if (rowsplit && mode != DL_ARGMAX && mt > 1 && nwg * mt <= 512) { gz = (unsigned)mt; mt = 1; }
   if (mode == DL_ARGMAX && ft == 2)
     rc = dl_launch<PM_ACT_NONE, 2>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                               (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
@@ -798,11 +807,11 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
                               (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                               (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   else if (act == PM_ACT_GELU)
-    rc = dl_launch<PM_ACT_GELU, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+    rc = dl_launch<PM_ACT_GELU, 1>(mt, dim3(nwg, 1, gz), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                            (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   else
-    rc = dl_launch<PM_ACT_NONE, 1>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+    rc = dl_launch<PM_ACT_NONE, 1>(mt, dim3(nwg, 1, gz), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                            (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   if (rc != PM_OK) return rc;
@@ -813,7 +822,8 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
 /* pm_dec_linear in plain mode (no LayerNorm) with K split over k_split (2..8) workgroups per 16-feature tile: each part
  * reads 1 / k_split of x and of its weight rows; the last part to finish (agent-scope ticket, no spinning) adds the parts
  * in part order and applies bias / activation / residual.  split_ws: ceil(N / 16) * k_split * mt * 256 floats (mt = ceil(M / 16) rounded up to 1, 2 or 4);
- * split_cnt: ceil(N / 16) int32, zero before the first launch and zero again after every launch. */
+ * split_cnt: ceil(N / 16) * 4 int32 (a ticket per feature tile and row tile), zero before the first launch and zero
+ * again after every launch. */
 extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
                                     const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
                                     int act, int64_t k_split, float* split_ws, int32_t* split_cnt, void* stream) {
@@ -825,10 +835,13 @@ extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, 
   if (ldo < N || (resid && ldr < N)) return PM_EINVAL;
   if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
   const int nwg = (int)((N + DL_FEATS - 1) / DL_FEATS);
-  const int mt = (int)((M + 15) / 16);
+  int mt = (int)((M + 15) / 16);
+  static const bool rowsplit = [] { const char* e = getenv("PM_DEC_ROWSPLIT"); return !e || atoi(e) != 0; }();
+  unsigned gz = 1;
+  if (rowsplit && mt > 1 && nwg * mt * k_split <= 1024) { gz = (unsigned)mt; mt = 1; }
   const int k_eff = (int)(((K / 32 + k_split - 1) / k_split) * 32);  // the longest part decides the instantiation
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(nwg, (unsigned)k_split);
+  const dim3 grid(nwg, (unsigned)k_split, gz);
   int rc;
   // (dl_launch picks NSTEP from its K argument; the kernel takes the true K from its own parameter list, so pass
   // k_eff only for that choice: both instantiations below receive the real K)

@@ -330,7 +330,7 @@ def dec_linear_ksplit(x: Tensor, w: Tensor, bias: Tensor | None = None, *, k_spl
     nt, mt = (N + 15) // 16, (M + 15) // 16
     mt = 1 if mt <= 1 else 2 if mt == 2 else 4  # row tiles of the kernel instantiation
     ws = torch.empty(nt * k_split * mt * 256, dtype=torch.float32, device=x.device)
-    cnt = torch.zeros(nt, dtype=torch.int32, device=x.device)
+    cnt = torch.zeros(nt * 4, dtype=torch.int32, device=x.device)  # one ticket per (feature tile, row tile)
     rc = lib().pm_dec_linear_ksplit(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
                                     resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
                                     out.data_ptr(), out.stride(0), M, N, K, ACT[act], k_split, ws.data_ptr(), cnt.data_ptr(), _stream())

@@ -85,7 +85,7 @@ class GreedyDecoder:
             nt, mt = (N + 15) // 16, (B + 15) // 16
             mt = 1 if mt <= 1 else 2 if mt == 2 else 4  # row tiles of the kernel instantiation
             ws = torch.empty(nt * ksp * mt * 256, **f32)
-            cnt = torch.zeros(nt, dtype=torch.int32, device=dev)
+            cnt = torch.zeros(nt * 4, dtype=torch.int32, device=dev)  # one ticket per (feature tile, row tile)
             self._ks_bufs += [ws, cnt]
             self._keep += [w, bias]
             add(L.pm_dec_linear_ksplit, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _ptr(bias), _ptr(resid),
