@@ -111,8 +111,10 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
                 dec.step(dlog if i % 8 == 0 else None)  # sample every 8th step: keeps the event count bounded
             torch.cuda.synchronize()
         S, d = memory.shape[1], memory.shape[2]
-        att = dlog["pm_dec_attention_fused"]
+        att = dlog.get("pm_dec_attention_fused", [])
         cross = [(a, b) for a, b, ar in att if ar[18] == 0]  # self_attn == 0 <=> cross-attention block
+        if not cross:  # unfused launch list (experiments): the plain attention launches over the memory keys
+            cross = [(a, b) for a, b, ar in dlog.get("pm_dec_attention", []) if ar[6] is None]
         cross_ms = sum(a.elapsed_time(b) for a, b in cross)
         # algorithmic bytes per launch: packed cross K/V (bf16) + x, out (f32) + the q projection weight once
         cross_bytes = len(cross) * (2 * B * S * d * 2 + 2 * B * d * 4 + d * d * 2)

@@ -117,7 +117,9 @@ class GreedyDecoder:
             wqkv, bqkv = sa._pack("qkv")
             g, b = _f32(layer.sa_norm, "g", layer.sa_norm.weight), _f32(layer.sa_norm, "b", layer.sa_norm.bias)
             self._keep += [wqkv, bqkv, g, b]
-            if fused:  # LN + q/k/v projection + cache append + attention in one launch per layer
+            fuse_self = fused and os.environ.get("PM_DEC_FUSE_SELF", "1") != "0"
+            fuse_cross = fused and os.environ.get("PM_DEC_FUSE_CROSS", "1") != "0"
+            if fuse_self:  # LN + q/k/v projection + cache append + attention in one launch per layer
                 add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
                     wqkv.data_ptr(), _ptr(bqkv), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64, self.pos.data_ptr(),
                     0, Tmax, self.att.data_ptr(), B, H, 1, None)
@@ -136,7 +138,7 @@ class GreedyDecoder:
             g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
             bq = _f32(ca.q_proj, "b", ca.q_proj.bias)
             self._keep += [g, b, bq]
-            if fused:
+            if fuse_cross:
                 add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
                     ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
                     2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
