@@ -162,7 +162,7 @@ int pm_dec_embed(const int64_t* tok_cur, const void* emb, const float* pos, cons
  * mode 1 (N = 3*inner, [q|k|v] blocks): q -> out f32 (M, inner); k, v -> bf16 caches (M, H, Tmax, 64) at position t;
  * mode 2: no store - per row, the tile's (max logit, lowest index) go to ws_val / ws_idx (M, ceil(N / tile)),
  *         tile = pm_dec_argmax_tile(K) features.  With LayerNorm: K <= 1280.
- * act: PM_ACT_NONE | PM_ACT_GELU (erff).  K % 32 == 0. */
+ * act: PM_ACT_NONE | PM_ACT_GELU (erff) | PM_ACT_GELU_TANH (tanhf).  K % 32 == 0. */
 int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w,
                   int64_t ldw, const float* bias, const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M,
                   int64_t N, int64_t K, int act, int mode, void* kcache, void* vcache, int64_t inner, int64_t H,

@@ -785,7 +785,7 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
   } else {
     return PM_EINVAL;
   }
-  if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
+  if (act != PM_ACT_NONE && act != PM_ACT_GELU && act != PM_ACT_GELU_TANH) return PM_EUNSUPPORTED;
   if (K > 1280 && gamma) return PM_EUNSUPPORTED;
   const int per_wave = (int)((K / 32 + 3) / 4);
   const int ft = mode == DL_ARGMAX ? (gamma && per_wave > 4 ? 2 : 4) : 1;  // see pm_dec_argmax_tile()
@@ -806,6 +806,10 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
     rc = dl_launch<PM_ACT_NONE, 4>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                               (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                               (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
+  else if (act == PM_ACT_GELU_TANH)
+    rc = dl_launch<PM_ACT_GELU_TANH, 1>(mt, dim3(nwg, 1, gz), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
+                           (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
+                           (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);
   else if (act == PM_ACT_GELU)
     rc = dl_launch<PM_ACT_GELU, 1>(mt, dim3(nwg, 1, gz), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                            (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,

@@ -30,9 +30,12 @@ class GreedyDecoder:
         E = dec.token_embs.weight
         if E.dtype != torch.bfloat16 or not E.is_cuda:
             raise NotImplementedError("greedy decode: bf16 weights on a HIP device only (model.to(torch.bfloat16).cuda())")
-        if memory.dtype != torch.bfloat16 or memory.dim() != 3:
-            raise ValueError("greedy decode: memory must be the encoder's bf16 (B, S, d) output")
-        B, S, d = memory.shape
+        if memory is None:  # decoder-only language model (GPT-2): no cross-attention, nothing to attend to but itself
+            B, S, d = prompt.shape[0], 0, E.shape[1]
+        else:
+            if memory.dtype != torch.bfloat16 or memory.dim() != 3:
+                raise ValueError("greedy decode: memory must be the encoder's bf16 (B, S, d) output")
+            B, S, d = memory.shape
         P = prompt.shape[1]
         if prompt.shape[0] != B or prompt.dtype != torch.int64 or P < 1:
             raise ValueError("greedy decode: prompt must be int64 (B, P >= 1)")
@@ -44,7 +47,7 @@ class GreedyDecoder:
             raise ValueError(f"greedy decode: {self.Ttot} positions > max_seq_len {dec.pos_embs.shape[0]}")
         if B > 64:
             raise NotImplementedError("greedy decode: at most 64 sequences per call (shard larger batches)")
-        dev = memory.device
+        dev = E.device
         H = dec.layers[0].sa.n_heads
         inner = H * 64
         if dec.layers[0].sa.head_dim != 64 or inner != d:
@@ -68,7 +71,7 @@ class GreedyDecoder:
         self.ws_val = torch.empty(B, n_tiles, **f32)
         self.ws_idx = torch.empty(B, n_tiles, dtype=torch.int32, device=dev)
         pos_f32 = _f32(dec, "pos", dec.pos_embs)
-        mem2 = memory.reshape(B * S, d)
+        mem2 = memory.reshape(B * S, d) if memory is not None else None
         self._keep = [E, pos_f32, memory]  # tensors the launch list points into
         self.launches = []  # (fn, args): raw pointers only -> the loop has no per-step Python work beyond ctypes
 
@@ -107,8 +110,10 @@ class GreedyDecoder:
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         self.self_k, self.self_v, self.cross_kv, self._cross_w = [], [], [], []
         for layer in dec.layers:
-            if not layer.pre_norm or layer.ca is None:
-                raise NotImplementedError("greedy decode: pre-norm layers with cross-attention only")
+            if not layer.pre_norm:
+                raise NotImplementedError("greedy decode: pre-norm layers only (the post-norm GPT decodes through forward())")
+            if (layer.ca is None) != (memory is None):
+                raise ValueError("greedy decode: cross-attention layers need a memory, decoder-only layers must not get one")
             sa, ca, mlp = layer.sa, layer.ca, layer.mlp
             kc = torch.empty(B, H, Tmax, 64, dtype=torch.bfloat16, device=dev)
             vc = torch.empty_like(kc)
@@ -129,31 +134,33 @@ class GreedyDecoder:
                     self.pos.data_ptr(), 1, Tmax, self.att.data_ptr(), B, H, None)
             dec_linear(self.att, inner, None, None, 0.0, sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), self.x,
                        self.x, d)
-            # cross attention: K/V of the memory projected ONCE (the reference re-projects them on every call,
-            # transformer.py:44-49), kept packed (B, S, [k | v]) in bf16
-            wkv, bkv = ca._pack("kv")
-            kv = ops.linear(mem2, wkv, bkv)
-            self.cross_kv.append(kv)
-            self._cross_w.append((wkv, bkv))
-            g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
-            bq = _f32(ca.q_proj, "b", ca.q_proj.bias)
-            self._keep += [g, b, bq]
-            if fuse_cross:
-                add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
-                    ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
-                    2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
-            else:
-                dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, bq, None, self.q, inner)
-                add(L.pm_dec_attention, self.q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
-                    2 * inner, None, S, S, self.att.data_ptr(), B, H, None)
-            dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), self.x,
-                       self.x, d)
+            if ca is not None:
+                # cross attention: K/V of the memory projected ONCE (the reference re-projects them on every call,
+                # transformer.py:44-49), kept packed (B, S, [k | v]) in bf16
+                wkv, bkv = ca._pack("kv")
+                kv = ops.linear(mem2, wkv, bkv)
+                self.cross_kv.append(kv)
+                self._cross_w.append((wkv, bkv))
+                g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
+                bq = _f32(ca.q_proj, "b", ca.q_proj.bias)
+                self._keep += [g, b, bq]
+                if fuse_cross:
+                    add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
+                        ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
+                        2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
+                else:
+                    dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, bq, None, self.q, inner)
+                    add(L.pm_dec_attention, self.q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
+                        2 * inner, None, S, S, self.att.data_ptr(), B, H, None)
+                dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), self.x,
+                           self.x, d)
             g, b = _f32(layer.mlp_norm, "g", layer.mlp_norm.weight), _f32(layer.mlp_norm, "b", layer.mlp_norm.bias)
-            if mlp.act_name != "gelu":
-                raise NotImplementedError("greedy decode: GELU MLP only")
+            if mlp.act_name not in ("gelu", "approximate_gelu"):
+                raise NotImplementedError("greedy decode: GELU / tanh-GELU MLPs only")
+            act_code = ops.ACT[mlp.act_name]
             hid = mlp.linear1.out_features
             dec_linear(self.x, d, g, b, layer.mlp_norm.eps, mlp.linear1.weight, _f32(mlp.linear1, "b", mlp.linear1.bias), None,
-                       self.h[:, :hid], hid, act=1)
+                       self.h[:, :hid], hid, act=act_code)
             dec_linear(self.h[:, :hid], hid, None, None, 0.0, mlp.linear2.weight, _f32(mlp.linear2, "b", mlp.linear2.bias),
                        self.x, self.x, d)
         g, b = _f32(dec.norm, "g", dec.norm.weight), _f32(dec.norm, "b", dec.norm.bias)
@@ -166,12 +173,14 @@ class GreedyDecoder:
     def rebind(self, memory: Tensor, prompt: Tensor) -> None:
         """New clips, same geometry: re-project the cross K/V INTO the existing buffers and swap the prompt, so the
         captured graph (which holds raw pointers) stays valid."""
-        B, S, d = memory.shape
-        assert (B, self.P) == tuple(prompt.shape) and B == self.B and memory.dtype == torch.bfloat16
-        mem2 = memory.reshape(B * S, d)
-        for kv, (wkv, bkv) in zip(self.cross_kv, self._cross_w):
-            assert kv.shape[0] == B * S
-            ops.linear(mem2, wkv, bkv, out=kv)
+        assert (self.B, self.P) == tuple(prompt.shape)
+        if memory is not None:
+            B, S, d = memory.shape
+            assert B == self.B and memory.dtype == torch.bfloat16
+            mem2 = memory.reshape(B * S, d)
+            for kv, (wkv, bkv) in zip(self.cross_kv, self._cross_w):
+                assert kv.shape[0] == B * S
+                ops.linear(mem2, wkv, bkv, out=kv)
         self.prompt.copy_(prompt)
         self.tokens[:, : self.P] = self.prompt
 

@@ -1,0 +1,48 @@
+"""Text generation for decoder-only models: drop-in for /root/reference pytorch_models/text/generator.py
+(DecoderGenerator(model, tokenizer).generate(prompt, max_tokens, topk)).
+
+topk == 1 (greedy) on a pre-norm model (GPT-2) runs the KV-cached decode-step kernels of audio2text/generate.py - the
+reference re-runs the whole sequence for every new token (generator.py:24-25, O(T^2)); post-norm models (GPT) and
+top-k sampling re-run the HIP forward per token like the reference does.  The tokenizer is any object with
+``encode(str) -> list[int]``, ``decode(list[int]) -> str`` and ``eos_token_id`` (no tokenizer ships with this build)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+class DecoderGenerator:
+    def __init__(self, model: nn.Module, tokenizer) -> None:
+        self.model = model
+        self.tokenizer = tokenizer
+
+    @torch.inference_mode()
+    def generate_ids(self, tokens: list[int], max_tokens: int = 100, topk: int = 1, eos_token_id: int | None = None,
+                     generator: torch.Generator | None = None) -> list[int]:
+        """Token-level form of generate(): prompt ids -> prompt + new ids, stopping after eos_token_id (kept, as the
+        reference keeps it) or max_tokens new tokens."""
+        device = next(self.model.parameters()).device
+        tokens = list(tokens)
+        n = len(tokens)
+        if topk == 1 and hasattr(self.model, "generate") and all(l.pre_norm for l in self.model.layers):
+            room = self.model.pos_embs.shape[0] - n
+            out = self.model.generate(torch.tensor([tokens], device=device), min(max_tokens, room))[0].tolist()
+            new = out[n:]
+            if eos_token_id is not None and eos_token_id in new:
+                new = new[: new.index(eos_token_id) + 1]
+            return tokens + new
+        while len(tokens) - n < max_tokens:
+            logits = self.model(torch.tensor(tokens, device=device))[-1]
+            if topk == 1:
+                token = int(logits.argmax(-1))
+            else:  # top-k sampling (generator.py:30-32)
+                vals, idx = logits.topk(topk)
+                token = int(idx[torch.multinomial(vals.softmax(-1), 1, generator=generator)])
+            tokens.append(token)
+            if eos_token_id is not None and token == eos_token_id:
+                break
+        return tokens
+
+    def generate(self, prompt: str, max_tokens: int = 100, topk: int = 1) -> str:
+        ids = self.generate_ids(self.tokenizer.encode(prompt), max_tokens, topk, getattr(self.tokenizer, "eos_token_id", None))
+        return self.tokenizer.decode(ids)

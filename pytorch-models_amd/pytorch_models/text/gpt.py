@@ -1,0 +1,57 @@
+"""GPT (the 2018 model) on MI355X: drop-in for /root/reference pytorch_models/text/gpt.py (GPT, from_openai; parameter
+names token_embs, pos_embs, layers).  Post-norm causal decoder with tanh-GELU, no final norm, tied logits."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from ..transformer import Decoder
+from .gpt2 import _lm_forward
+
+
+class GPT(nn.Module):
+    vocab_size = 40478
+    max_seq_len: int = 512
+
+    def __init__(self, n_layers: int = 12, d_model: int = 768, dropout: float = 0.0) -> None:
+        super().__init__()
+        self.token_embs = nn.Embedding(self.vocab_size, d_model)
+        self.pos_embs = nn.Parameter(torch.zeros(self.max_seq_len, d_model))
+        self.layers = Decoder(n_layers, d_model, dropout=dropout, pre_norm=False, act="approximate_gelu")
+
+    def forward(self, x: Tensor) -> Tensor:
+        """token ids (..., L) int64 -> logits (..., L, 40478) fp32 (gpt.py:24-29)."""
+        return _lm_forward(self, x, None)
+
+    @staticmethod
+    def from_openai(*, pretrained=False, **kwargs) -> "GPT":
+        m = GPT(**kwargs)
+        if pretrained:
+            raise NotImplementedError(
+                "GPT.from_openai(pretrained=True) needs a network download, which this build does not do; construct with "
+                "pretrained=False and call load_openai_params(list of arrays in params_shapes.json order).")
+        return m
+
+    @torch.no_grad()
+    def load_openai_params(self, params) -> None:
+        """The flat parameter list of openai/finetune-transformer-lm (pos, tokens, then 12 tensors per layer), already
+        split and reshaped as gpt.py:40-52 does; placement as gpt.py:54-84."""
+        params = [torch.as_tensor(p) for p in params]
+        self.pos_embs.copy_(params[0])
+        self.token_embs.weight[: params[1].shape[0]] = params[1]
+        n = 12
+        for i, layer in enumerate(self.layers):
+            q = params[2 + i * n: 2 + (i + 1) * n]
+            for proj, w, b in zip((layer.sa.q_proj, layer.sa.k_proj, layer.sa.v_proj), q[0].squeeze(0).chunk(3, -1), q[1].chunk(3, -1)):
+                proj.weight.copy_(w.T)
+                proj.bias.copy_(b)
+            layer.sa.out_proj.weight.copy_(q[2].squeeze(0).T)
+            layer.sa.out_proj.bias.copy_(q[3])
+            layer.sa_norm.weight.copy_(q[4])
+            layer.sa_norm.bias.copy_(q[5])
+            layer.mlp.linear1.weight.copy_(q[6].squeeze(0).T)
+            layer.mlp.linear1.bias.copy_(q[7])
+            layer.mlp.linear2.weight.copy_(q[8].squeeze(0).T)
+            layer.mlp.linear2.bias.copy_(q[9])
+            layer.mlp_norm.weight.copy_(q[10])
+            layer.mlp_norm.bias.copy_(q[11])

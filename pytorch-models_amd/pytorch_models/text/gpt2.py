@@ -1,0 +1,89 @@
+"""GPT-2 on MI355X: drop-in for /root/reference pytorch_models/text/gpt2.py (GPT2, from_hf, load_hf_state_dict; parameter
+names token_embs, pos_embs, layers, norm).
+
+forward = pm_embed_tokens (token + position rows in one kernel) -> Decoder of pre-norm, causal, tanh-GELU layers
+(transformer.py) -> LayerNorm -> logits against the tied embedding matrix (pm_linear_bf16, fp32 out, ragged N = 50257).
+Greedy generation with a KV cache: GPT2.generate / text.DecoderGenerator (generate.py's decode-step kernels)."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from .._hip import ops
+from ..transformer import Decoder, LayerNorm, _f32
+
+_SIZES = {"gpt2": (12, 768), "gpt2-medium": (24, 1024), "gpt2-large": (36, 1280), "gpt2-xl": (48, 1600)}
+
+
+def _lm_forward(m, tokens: Tensor, final_norm) -> Tensor:
+    E = m.token_embs.weight
+    if E.dtype != torch.bfloat16:
+        raise NotImplementedError(f"{type(m).__name__}: only the bf16 path is built; use model.to(torch.bfloat16)")
+    lead = tokens.shape
+    tok2 = tokens.reshape(-1, lead[-1])  # the reference also accepts an unbatched (L,) sequence (generator.py:25)
+    h = ops.embed_tokens(tok2, E, _f32(m, "pos", m.pos_embs))
+    h = m.layers(h)
+    if final_norm is not None:
+        h = final_norm(h)
+    logits = ops.linear(h.view(-1, h.shape[-1]), E, None, out_dtype=torch.float32)
+    return logits.view(*lead, E.shape[0])
+
+
+class GPT2(nn.Module):
+    vocab_size = 50257
+    max_seq_len: int = 1024
+
+    def __init__(self, n_layers: int, d_model: int, dropout: float = 0.0) -> None:
+        super().__init__()
+        self.token_embs = nn.Embedding(self.vocab_size, d_model)
+        self.pos_embs = nn.Parameter(torch.zeros(self.max_seq_len, d_model))
+        self.layers = Decoder(n_layers, d_model, dropout=dropout, act="approximate_gelu")
+        self.norm = LayerNorm(d_model)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """token ids (..., L) int64 -> logits (..., L, 50257) fp32 (gpt2.py:21-27)."""
+        return _lm_forward(self, x, self.norm)
+
+    @torch.no_grad()
+    def generate(self, prompt: Tensor, max_new_tokens: int, *, graph: bool = True) -> Tensor:
+        """Batched greedy decoding with a KV cache: (B, P) int64 prompt -> (B, P + max_new_tokens) ids."""
+        from ..audio2text.generate import greedy_decode
+
+        return greedy_decode(self, None, prompt, max_new_tokens, graph=graph)
+
+    @staticmethod
+    def from_hf(model_tag: str, *, pretrained=False, **kwargs) -> "GPT2":
+        n_layers, d_model = _SIZES[model_tag]
+        m = GPT2(n_layers, d_model, **kwargs)
+        if pretrained:
+            raise NotImplementedError(
+                "GPT2.from_hf(pretrained=True) needs a network download, which this build does not do; construct with "
+                "pretrained=False and call load_hf_state_dict(torch.load(path, weights_only=True)).")
+        return m
+
+    @torch.no_grad()
+    def load_hf_state_dict(self, state_dict: dict[str, Tensor]) -> None:
+        """Hugging Face GPT2LMHeadModel state_dict (Conv1D weights are (in, out): transposed here; c_attn split in three)."""
+        sd = {k.removeprefix("transformer."): v for k, v in state_dict.items()}
+
+        def put(module, prefix: str) -> None:
+            w = sd.pop(f"{prefix}.weight")
+            module.weight.copy_(w.T if w.ndim == 2 else w)
+            if module.bias is not None:
+                module.bias.copy_(sd.pop(f"{prefix}.bias"))
+
+        wte = sd.pop("wte.weight")
+        self.token_embs.weight[: wte.shape[0]] = wte
+        self.pos_embs.copy_(sd.pop("wpe.weight"))
+        for i, layer in enumerate(self.layers):
+            p = f"h.{i}"
+            put(layer.sa_norm, f"{p}.ln_1")
+            put(layer.sa.out_proj, f"{p}.attn.c_proj")
+            for proj, w, b in zip((layer.sa.q_proj, layer.sa.k_proj, layer.sa.v_proj), sd.pop(f"{p}.attn.c_attn.weight").chunk(3, 1),
+                                  sd.pop(f"{p}.attn.c_attn.bias").chunk(3, 0)):
+                proj.weight.copy_(w.T)
+                proj.bias.copy_(b)
+            put(layer.mlp_norm, f"{p}.ln_2")
+            put(layer.mlp.linear1, f"{p}.mlp.c_fc")
+            put(layer.mlp.linear2, f"{p}.mlp.c_proj")
+        put(self.norm, "ln_f")

@@ -142,6 +142,70 @@ def openai_whisper(n_layers, d, n_mels, vocab, seed=0):
     return sd
 
 
+def hf_gpt2(n_layers, d, vocab, max_pos, seed=0):
+    """GPT2LMHeadModel layout: Conv1D weights are (in, out), c_attn packs q|k|v along the OUT axis, keys under transformer."""
+    sd = {}
+
+    def put(k, shape):
+        sd["transformer." + k] = _t(k, shape, seed)
+
+    put("wte.weight", (vocab, d))
+    put("wpe.weight", (max_pos, d))
+    for i in range(n_layers):
+        b = f"h.{i}."
+        for ln in ("ln_1", "ln_2"):
+            put(b + ln + ".weight", (d,))
+            put(b + ln + ".bias", (d,))
+        put(b + "attn.c_attn.weight", (d, 3 * d))
+        put(b + "attn.c_attn.bias", (3 * d,))
+        put(b + "attn.c_proj.weight", (d, d))
+        put(b + "attn.c_proj.bias", (d,))
+        put(b + "mlp.c_fc.weight", (d, 4 * d))
+        put(b + "mlp.c_fc.bias", (4 * d,))
+        put(b + "mlp.c_proj.weight", (4 * d, d))
+        put(b + "mlp.c_proj.bias", (d,))
+    put("ln_f.weight", (d,))
+    put("ln_f.bias", (d,))
+    return sd
+
+
+def hf_bert(n_layers, d, vocab, max_pos, *, roberta: bool, seed=0):
+    """BertModel / RobertaModel layout (nn.Linear weights (out, in)); RoBERTa carries two unused leading position rows."""
+    sd = {}
+    root = "roberta." if roberta else "bert."
+
+    def put(k, shape):
+        sd[root + k] = _t(k, shape, seed)
+
+    put("embeddings.word_embeddings.weight", (vocab, d))
+    put("embeddings.position_embeddings.weight", (max_pos + (2 if roberta else 0), d))
+    put("embeddings.token_type_embeddings.weight", (1 if roberta else 2, d))
+    put("embeddings.LayerNorm.weight", (d,))
+    put("embeddings.LayerNorm.bias", (d,))
+    for i in range(n_layers):
+        b = f"encoder.layer.{i}."
+        for name, shape in (("attention.self.query", (d, d)), ("attention.self.key", (d, d)), ("attention.self.value", (d, d)),
+                            ("attention.output.dense", (d, d)), ("intermediate.dense", (4 * d, d)), ("output.dense", (d, 4 * d))):
+            put(b + name + ".weight", shape)
+            put(b + name + ".bias", (shape[0],))
+        for ln in ("attention.output.LayerNorm", "output.LayerNorm"):
+            put(b + ln + ".weight", (d,))
+            put(b + ln + ".bias", (d,))
+    return sd
+
+
+def openai_gpt_params(n_layers, d, vocab, max_pos, seed=0):
+    """openai/finetune-transformer-lm parameter list after the reference's split / reshape (gpt.py:40-52): positions,
+    tokens, then per layer [c_attn w (1, d, 3d), b, c_proj w (1, d, d), b, ln_1 g, b, c_fc w (1, d, 4d), b, c_proj w
+    (1, 4d, d), b, ln_2 g, b]."""
+    ps = [_t("pos", (max_pos, d), seed), _t("tok", (vocab, d), seed)]
+    for i in range(n_layers):
+        for j, shape in enumerate(((1, d, 3 * d), (3 * d,), (1, d, d), (d,), (d,), (d,), (1, d, 4 * d), (4 * d,), (1, 4 * d, d), (d,),
+                                   (d,), (d,))):
+            ps.append(_t(f"l{i}.{j}", shape, seed))
+    return ps
+
+
 def state_digest(sd) -> dict:
     """name -> [sum, sum |x|, position-weighted sum] (fp64) of every tensor of a loaded model."""
     out = {}

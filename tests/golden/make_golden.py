@@ -301,9 +301,60 @@ def g_converters():
     print("converters.json", os.path.getsize(os.path.join(HERE, "converters.json")) // 1024, "KiB")
 
 
+def g_text():
+    """GPT-2 / GPT / BERT forwards on synthweights at the sizes of the reference's own tests
+    (tests/text/test_gpt2.py:16, test_gpt.py:16, test_bert.py:16), the greedy loop of text/generator.py with a stub
+    tokenizer, and digests of what the reference's HF / OpenAI loaders make of synthetic upstream checkpoints."""
+    from pytorch_models.text import BERT, GPT, GPT2, DecoderGenerator
+
+    sys.path.insert(2, os.path.join(ROOT, "tests"))
+    import ckpt_synth as C
+
+    out, rec = {}, {}
+    tok = synth_tokens("text_tok", (2, 16), 2000, 71)
+    m = GPT2(2, 128).eval()
+    fill_module(m, 72)
+    lg = m(tok)  # (2, 16, 50257): keep every 101st vocabulary column, the argmax and an order-sensitive digest
+    out["gpt2_logits_s101"], out["gpt2_argmax"], out["gpt2_digest"] = lg[..., ::101], lg.argmax(-1), digest(lg)
+
+    class Tok:  # the reference's generator wants a tokenizer: ids <-> space-separated decimal strings
+        eos_token_id = -1
+
+        def encode(self, s):
+            return [int(t) for t in s.split()]
+
+        def decode(self, ids):
+            return " ".join(str(int(i)) for i in ids)
+
+    gen = DecoderGenerator(m, Tok())
+    out["gpt2_greedy"] = np.array([[int(t) for t in gen.generate(Tok().decode(tok[b, :6]), max_tokens=12, topk=1).split()] for b in range(2)])
+    m = GPT(2, 128).eval()
+    fill_module(m, 73)
+    lg = m(tok)
+    out["gpt_logits_s101"], out["gpt_argmax"], out["gpt_digest"] = lg[..., ::101], lg.argmax(-1), digest(lg)
+    m = BERT(2000, 2, 128).eval()
+    fill_module(m, 74)
+    out["bert_hidden"] = m(tok)
+    # loaders
+    m = GPT2(2, 128)
+    m.load_hf_state_dict(C.hf_gpt2(2, 128, GPT2.vocab_size, GPT2.max_seq_len, seed=75))
+    rec["hf_gpt2"] = C.state_digest(m.state_dict())
+    import io
+    from contextlib import redirect_stdout
+    for name, rob in (("hf_bert", False), ("hf_roberta", True)):
+        m = BERT(1024, 2, 128, max_seq_len=64)
+        with redirect_stdout(io.StringIO()):
+            m.load_hf_state_dict(C.hf_bert(2, 128, 1024, 64, roberta=rob, seed=76))
+        rec[name] = C.state_digest(m.state_dict())
+    save("text", dict(tok_seed=71), **out)
+    with open(os.path.join(HERE, "text_converters.json"), "w") as f:
+        json.dump(rec, f, indent=0, sort_keys=True)
+    print("text_converters.json", os.path.getsize(os.path.join(HERE, "text_converters.json")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters"]
+    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters", "text"]
     table = dict(blocks=g_blocks, mha=g_mha, sdpa=g_sdpa_alignment, vit=g_vit, audio=g_audio, whisper=g_whisper,
-                 geometry=g_geometry, converters=g_converters)
+                 geometry=g_geometry, converters=g_converters, text=g_text)
     for w in which:
         table[w]()

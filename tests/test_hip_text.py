@@ -1,0 +1,91 @@
+"""GPU parity of the text models through the C ABI: GPT-2, GPT and BERT forwards against the
+fp32 oracle on the same bf16-rounded weights and against the reference's own vectors (tests/golden/text.npz), and the
+KV-cached greedy generation of GPT-2 against the oracle's full-recompute greedy loop.
+
+bf16 tolerance as in test_hip_blocks.py: rel-L2 <= 2e-2 vs the oracle, 3e-2 vs the reference golden (fp32 weights)."""
+import pytest
+import torch
+
+from oracle import ref_text as RX
+from synthweights import bf16_round_, fill_module, synth_tokens
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def rel(got, want):
+    got, want = got.float().cpu(), want.float()
+    return ((got - want).norm() / want.norm()).item()
+
+
+def prep(m, seed):
+    fill_module(m, seed)
+    bf16_round_(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    return m.to(torch.bfloat16).cuda().eval(), sd
+
+
+def test_gpt2_gpt_bert_forward(golden):
+    from pytorch_models.text import BERT, GPT, GPT2
+
+    g = golden("text")
+    tok = synth_tokens("text_tok", (2, 16), 2000, 71)
+    for cls, args, seed, fwd, name in ((GPT2, (2, 128), 72, RX.gpt2, "gpt2"), (GPT, (2, 128), 73, RX.gpt, "gpt")):
+        m, sd = prep(cls(*args), seed)
+        lg = m(tok.cuda())
+        assert lg.dtype == torch.float32 and lg.shape == (2, 16, cls.vocab_size)
+        assert rel(lg, fwd(sd, tok)) < 2e-2
+        assert rel(lg[..., ::101], g[name + "_logits_s101"]) < 3e-2
+        assert m(tok[0].cuda()).shape == (16, cls.vocab_size)  # unbatched, as the reference's generator calls it
+    m, sd = prep(BERT(2000, 2, 128), 74)
+    h = m(tok.cuda())
+    assert h.shape == (2, 16, 128) and rel(h, RX.bert(sd, tok)) < 2e-2 and rel(h, g["bert_hidden"]) < 3e-2
+    with pytest.raises(NotImplementedError, match="bf16"):
+        GPT2(1, 64).cuda()(tok.cuda())
+
+
+def test_gpt2_kv_cached_greedy_matches_the_oracle_loop():
+    """GPT2.generate (decode-step kernels, graph replay) vs the oracle's full-recompute greedy loop on the same
+    bf16-rounded weights: identical ids, or a first difference only where the oracle's own top-2 margin is a near-tie."""
+    from pytorch_models.text import GPT2, DecoderGenerator
+
+    m, sd = prep(GPT2(2, 128), 72)
+    tok = synth_tokens("text_tok", (2, 16), 2000, 71)
+    P, n_new = 6, 24
+    got = m.generate(tok[:, :P].cuda(), n_new).cpu()
+    assert got.shape == (2, P + n_new) and torch.equal(got[:, :P], tok[:, :P])
+
+    def kv_round(name, t):  # the cache holds bf16 k / v (the rounding point of the decode kernels)
+        return t.to(torch.bfloat16).float() if name == "kv" else t
+
+    want, margins = RX.greedy(RX.gpt2, sd, tok[:, :P], n_new, rp=kv_round)
+    for b in range(2):
+        diff = (got[b] != want[b]).nonzero()
+        if len(diff):
+            t = int(diff[0])
+            assert float(margins[b, t - P]) < 2e-4, f"sequence {b}: ids differ at position {t} at a decisive margin"
+    assert torch.equal(m.generate(tok[:, :P].cuda(), n_new, graph=False).cpu(), got)  # eager == graph replay
+    # the reference-shaped front end: tokenizer in, text out; greedy goes through the same KV-cached path
+    class Tok:
+        eos_token_id = None
+
+        def encode(self, s):
+            return [int(t) for t in s.split()]
+
+        def decode(self, ids):
+            return " ".join(str(int(i)) for i in ids)
+
+    text = DecoderGenerator(m, Tok()).generate(Tok().decode(tok[0, :P]), max_tokens=n_new)
+    assert text == Tok().decode(got[0])
+
+
+def test_gpt2_size_geometry_runs_one_step():
+    """GPT-2 small geometry (12 x 768, 12 heads), batch 4: logits shape / finiteness and 8 greedy tokens in range."""
+    from pytorch_models.text import GPT2
+
+    m, _ = prep(GPT2.from_hf("gpt2"), 78)
+    tok = synth_tokens("text_tok_b", (4, 32), 50257, 79)
+    lg = m(tok.cuda())
+    assert lg.shape == (4, 32, 50257) and torch.isfinite(lg).all()
+    ids = m.generate(tok[:, :8].cuda(), 8)
+    assert ids.shape == (4, 16) and int(ids.min()) >= 0 and int(ids.max()) < 50257
