@@ -11,6 +11,12 @@
 // operand and the token tile as B, so an accumulator lane holds 4 consecutive features of one token:
 // the epilogue packs them into one 8-byte (bf16) or 16-byte (f32) store.
 #include "common.h"
+// Priority: waves 4-7 (the younger wave of each SIMD pair, which loses every age-based arbitration and made waves 0-3
+// wait ~600-1200 cycles at each barrier) run at s_setprio 1 for the whole kernel; no per-step flips
+// (MI355X_MICROARCH.md, two waves per SIMD, item 4).  out_proj -4.5 %, fc2 -3 %, fc1 / QKV -1 %.  0 = the old flips.
+#ifndef PM_STATIC_PRIO
+#define PM_STATIC_PRIO 1
+#endif
 
 // linear_bf16_wide.hip
 int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
@@ -267,6 +273,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if PM_STATIC_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   PM_STAGE_NEXT();
   PM_STAGE_NEXT();
   const int fr = lane & 15, fq = lane >> 4;
@@ -322,7 +331,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
         for (int i = 0; i < 4; ++i) b[s][i] = read_frag(xcur, wm * 64 + i * 16 + fr, s * 4 + fq);
       }
       __builtin_amdgcn_sched_barrier(0);
+#if !PM_STATIC_PRIO
       __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s == 0 && kt == 0) {  // a tile's first MFMAs start from the constant 0: no accumulator clearing anywhere
@@ -339,7 +350,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
               acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][j], b[s][i], acc[j][i], 0, 0, 0);
         }
       }
+#if !PM_STATIC_PRIO
       __builtin_amdgcn_s_setprio(0);
+#endif
     }
     const int cbuf = buf;
     buf = buf == 2 ? 0 : buf + 1;

@@ -24,6 +24,12 @@ constexpr int WBM = 256, WBN = 256, WBK = 32;
 constexpr int WSTAGE = (WBM + WBN) * WBK * 2;  // 32 KiB
 constexpr int WRING = 4;
 constexpr int WGROUP_M = 4;
+// Priority: waves 4-7 (the younger wave of each SIMD pair, which loses every age-based arbitration and made waves 0-3
+// wait ~600-1200 cycles at each barrier) run at s_setprio 1 for the whole kernel; no per-step flips
+// (MI355X_MICROARCH.md, two waves per SIMD, item 4).  out_proj -4.5 %, fc2 -3 %, fc1 / QKV -1 %.  0 = the old flips.
+#ifndef PM_STATIC_PRIO
+#define PM_STATIC_PRIO 1
+#endif
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ (((row >> 3) & 1) * 3); }
 
@@ -97,6 +103,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if PM_STATIC_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the younger wave of each SIMD pair loses every arbitration otherwise
+#endif
   PM_WSTAGE_NEXT();
   PM_WSTAGE_NEXT();
   PM_WSTAGE_NEXT();
@@ -132,7 +141,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = wread(wcur, wn * 128 + j * 16 + fr, fq);
       __builtin_amdgcn_sched_barrier(0);
+#if !PM_STATIC_PRIO
       __builtin_amdgcn_s_setprio(1);
+#endif
       if (kt == 0) {  // a tile's first step starts from the constant 0: nobody has to clear 128 accumulator registers
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -145,7 +156,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
       }
+#if !PM_STATIC_PRIO
       __builtin_amdgcn_s_setprio(0);
+#endif
     }
     const int cbuf = buf;
     buf = (buf + 1) & (WRING - 1);
