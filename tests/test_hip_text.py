@@ -79,6 +79,22 @@ def test_gpt2_kv_cached_greedy_matches_the_oracle_loop():
     assert text == Tok().decode(got[0])
 
 
+@pytest.mark.parametrize("B", [1, 17, 64])
+def test_gpt2_greedy_batch_sizes(B):
+    """One sequence, a ragged 17 and the 64-sequence maximum (1, 2 and 4 row tiles of the decode projections): every
+    sequence decodes exactly as it does alone in a batch of one (batch invariance of the KV-cached path)."""
+    from pytorch_models.text import GPT2
+
+    m, _ = prep(GPT2(2, 128), 72)
+    tok = synth_tokens("text_tok_many", (64, 8), 2000, 80)[:B]
+    got = m.generate(tok.cuda(), 12).cpu()
+    assert got.shape == (B, 20)
+    for b in sorted({0, B // 2, B - 1}):
+        assert torch.equal(m.generate(tok[b:b + 1].cuda(), 12).cpu()[0], got[b]), b
+    with pytest.raises(NotImplementedError, match="64 sequences"):
+        m.generate(synth_tokens("text_tok_65", (65, 4), 2000, 81).cuda(), 2)
+
+
 def test_gpt2_size_geometry_runs_one_step():
     """GPT-2 small geometry (12 x 768, 12 heads), batch 4: logits shape / finiteness and 8 greedy tokens in range."""
     from pytorch_models.text import GPT2
