@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
   // wave, no bias) skip the per-score compare / select work - a third of the VALU instructions of a tile, and this
   // kernel is VALU-bound (SQ counters at L = 1500: vector ALU active 79 % of the time, matrix pipe 31 %) - and only the
   // trailing tiles run the masked form.  Both forms stage K/V and hit the barrier identically.
-#define PM_ATT_TILE(MASKED)                                                                                              \
-    const char* kbuf = smem + (t & 1) * 2 * TILE_B;                                                                      \
+#define PM_ATT_TILE(MASKED, PAR)                                                                                         \
+    const char* kbuf = smem + (PAR) * 2 * TILE_B;                                                                        \
     const char* vbuf = kbuf + TILE_B;                                                                                    \
     if (t + 1 < nT) load_tile(t + 1);                                                                                    \
     /* work that cannot contribute is skipped per wave (the K/V staging and the barrier are not): a wave whose 32 */     \
@@ -137,7 +137,7 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                        \
       for (int i = 0; i < 16; ++i) {                                                                                     \
         if (kb == 1 && !kb1) continue;                                                                                   \
-        float v = sc[kb][i] * c;                                                                                         \
+        float v = (MASKED) ? sc[kb][i] * c : sc[kb][i];  /* mask-free tiles keep RAW scores: max(c s) = c max(s) */      \
         if constexpr (BIAS) {  /* additive attn_bias[b, h, q, k] (strides may be 0 = broadcast), natural-log units */    \
           const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);                                                   \
           if (key < Lk) v = fmaf(bias_row[key], 1.4426950408889634f, v);                                                 \
@@ -150,6 +150,7 @@ _Pragma("unroll")                                                               
         mx = fmaxf(mx, v);                                                                                               \
       }                                                                                                                  \
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                              \
+    if (!(MASKED)) mx *= c;                                                                                              \
     const float m_new = fmaxf(m_run, mx);                                                                                \
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                           \
     m_run = m_new;                                                                                                       \
@@ -159,7 +160,8 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                        \
       for (int i = 0; i < 16; ++i) {                                                                                     \
         if (kb == 1 && !kb1) continue;                                                                                   \
-        const float p = __builtin_amdgcn_exp2f(sc[kb][i] - m_new);                                                       \
+        /* mask-free: the scale rides in the exponent's fma, exp2(fma(s, c, -max)) - no multiply per score */            \
+        const float p = __builtin_amdgcn_exp2f((MASKED) ? sc[kb][i] - m_new : fmaf(sc[kb][i], c, -m_new));               \
         sc[kb][i] = p;                                                                                                   \
         ps += p;                                                                                                         \
       }                                                                                                                  \
@@ -186,7 +188,7 @@ _Pragma("unroll")                                                               
         }                                                                                                                \
       }                                                                                                                  \
     }                                                                                                                    \
-    if (t + 1 < nT) write_tile(smem + ((t + 1) & 1) * 2 * TILE_B);                                                       \
+    if (t + 1 < nT) write_tile(smem + ((PAR) ^ 1) * 2 * TILE_B);                                                         \
     __syncthreads();                                                                                                     \
   /* end of PM_ATT_TILE */
   int n_plain = BIAS ? 0 : (Lk / KV_TILE < nT ? Lk / KV_TILE : nT);  // leading tiles whose 64 keys all exist
@@ -194,9 +196,19 @@ _Pragma("unroll")                                                               
     const int below = (q0 + wave * 32 + 1) / KV_TILE;
     n_plain = below < n_plain ? below : n_plain;
   }
+  // the mask-free loop is unrolled by two so that the LDS buffer of a tile is a compile-time constant (the fragment and
+  // transposed-read addresses become base + immediate instead of ~36 integer instructions per tile)
   int t = 0;
-  for (; t < n_plain; ++t) { PM_ATT_TILE(false) }
-  for (; t < nT; ++t) { PM_ATT_TILE(true) }
+  for (; t + 1 < n_plain; ++t) {
+    { PM_ATT_TILE(false, 0) }
+    ++t;
+    { PM_ATT_TILE(false, 1) }
+  }
+  if (t < n_plain) {  // t is even here
+    { PM_ATT_TILE(false, 0) }
+    ++t;
+  }
+  for (; t < nT; ++t) { PM_ATT_TILE(true, t & 1) }
 #undef PM_ATT_TILE
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
