@@ -509,7 +509,9 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || resid_period > (1 << 30)) return PM_EINVAL;
   hipStream_t st0 = (hipStream_t)stream;
   if (y_dtype == PM_BF16 && vec_ok && N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && !(resid && resid_dtype != PM_BF16) &&
-      !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) && pm_linear_bf16_wide_applies(M, N, K, act)) {
+      !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) && pm_linear_bf16_wide_applies(M, N, K, act) &&
+      // the wide kernel keeps 32-bit element offsets per operand
+      (x_rows_per_batch > 0 ? (M / x_rows_per_batch + 1) * x_batch_stride : M * ldx) < (1LL << 32) && N * ldw < (1LL << 32)) {
     if (ln.row_out) return PM_EUNSUPPORTED;  // row partials are produced by the 256 x 128 kernel (N = d_model layers)
     const int rcw = pm_linear_bf16_wide_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
                                                ldy, M, N, K, act, ln, st0);

@@ -20,9 +20,15 @@
 
 namespace {
 
-constexpr int WBM = 256, WBN = 256, WBK = 32;
-constexpr int WSTAGE = (WBM + WBN) * WBK * 2;  // 32 KiB
-constexpr int WRING = 4;
+#ifndef PM_WIDE_BK
+#define PM_WIDE_BK 64  // 32 = the earlier form: 64-byte rows, four 32 KiB stages, a barrier per 32 of K
+#endif
+constexpr int WBM = 256, WBN = 256, WBK = PM_WIDE_BK;
+constexpr int WSTAGE = (WBM + WBN) * WBK * 2;  // 32 KiB (64 KiB at WBK = 64)
+constexpr int WRING = WBK == 32 ? 4 : 2;
+constexpr int WROWB = WBK * 2;          // bytes per LDS row
+constexpr int WPIECE_ROWS = 1024 / WROWB;  // rows per 1 KiB LDS-DMA piece: 16 or 8
+constexpr int WNPIECE = 32 / WPIECE_ROWS;  // pieces per operand and wave (32 rows each): 2 or 4
 constexpr int WGROUP_M = 4;
 // Priority: waves 4-7 (the younger wave of each SIMD pair, which loses every age-based arbitration and made waves 0-3
 // wait ~600-1200 cycles at each barrier) run at s_setprio 1 for the whole kernel; no per-step flips
@@ -34,7 +40,8 @@ constexpr int WGROUP_M = 4;
 __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ (((row >> 3) & 1) * 3); }
 
 __device__ __forceinline__ bf16x8 wread(const char* tile, int row, int chunk) {
-  return *(const bf16x8*)(tile + row * 64 + swz64(row, chunk) * 16);
+  if constexpr (WBK == 32) return *(const bf16x8*)(tile + row * 64 + swz64(row, chunk) * 16);
+  else return *(const bf16x8*)(tile + row * 128 + swz_pos(row, chunk) * 16);
 }
 
 __device__ __forceinline__ void wtile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -65,33 +72,34 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
   const int P = my_tiles * nk;
 
   // staging side of the stream (a macro over plain locals: see linear_bf16.hip)
-  int64_t xoff[2], woff[2];
+  uint32_t xoff[WNPIECE], woff[WNPIECE];  // element offsets (the dispatcher keeps this path under 2^32 elements per operand)
   int pp = 0, pp_kt = 0, pp_tile = 0, pp_buf = 0;
 #define PM_WSTAGE_NEXT()                                                                                             \
   if (pp < P) {                                                                                                      \
     if (pp_kt == 0) {                                                                                                \
       int tm_, tn_;                                                                                                  \
       wtile_coords(tbase + local + pp_tile * nloc, tiles_m, tiles_n, tm_, tn_);                                      \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-        const int rt = wave * 32 + i * 16 + (lane >> 2);                                                             \
-        const int chunk = swz64(rt, lane & 3);                                                                       \
+      _Pragma("unroll") for (int i = 0; i < WNPIECE; ++i) {                                                          \
+        const int rt = wave * 32 + i * WPIECE_ROWS + (WBK == 32 ? (lane >> 2) : (lane >> 3));                        \
+        const int chunk = WBK == 32 ? swz64(rt, lane & 3) : swz_pos(rt, lane & 7);                                   \
         int gm = tm_ * WBM + rt;                                                                                     \
         gm = gm < M ? gm : M - 1;                                                                                    \
         if (x_rows_per_batch > 0) {                                                                                  \
           const int bb = gm / x_rows_per_batch;                                                                      \
-          xoff[i] = (int64_t)bb * x_batch_stride + (int64_t)(gm - bb * x_rows_per_batch) * ldx + chunk * 8;          \
+          xoff[i] = (uint32_t)((int64_t)bb * x_batch_stride + (int64_t)(gm - bb * x_rows_per_batch) * ldx + chunk * 8); \
         } else {                                                                                                     \
-          xoff[i] = (int64_t)gm * ldx + chunk * 8;                                                                   \
+          xoff[i] = (uint32_t)((int64_t)gm * ldx + chunk * 8);                                                        \
         }                                                                                                            \
         int gn = tn_ * WBN + rt;                                                                                     \
         gn = gn < N ? gn : N - 1;                                                                                    \
-        woff[i] = (int64_t)gn * ldw + chunk * 8;                                                                     \
+        woff[i] = (uint32_t)((int64_t)gn * ldw + chunk * 8);                                                          \
       }                                                                                                              \
     }                                                                                                                \
     char* xs_ = smem + pp_buf * WSTAGE;                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) glds16(X + xoff[i] + pp_kt * WBK, xs_ + (wave * 32 + i * 16) * 64); \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
-        glds16(W + woff[i] + pp_kt * WBK, xs_ + WBM * 64 + (wave * 32 + i * 16) * 64);                                \
+    _Pragma("unroll") for (int i = 0; i < WNPIECE; ++i)                                                              \
+        glds16(X + xoff[i] + pp_kt * WBK, xs_ + (wave * 32 + i * WPIECE_ROWS) * WROWB);                               \
+    _Pragma("unroll") for (int i = 0; i < WNPIECE; ++i)                                                              \
+        glds16(W + woff[i] + pp_kt * WBK, xs_ + WBM * WROWB + (wave * 32 + i * WPIECE_ROWS) * WROWB);                 \
     ++pp;                                                                                                            \
     pp_buf = (pp_buf + 1) & (WRING - 1);                                                                             \
     if (++pp_kt == nk) { pp_kt = 0; ++pp_tile; }                                                                     \
@@ -107,17 +115,20 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the younger wave of each SIMD pair loses every arbitration otherwise
 #endif
   PM_WSTAGE_NEXT();
-  PM_WSTAGE_NEXT();
-  PM_WSTAGE_NEXT();
+  if (WRING == 4) { PM_WSTAGE_NEXT(); PM_WSTAGE_NEXT(); }
   const int fr = lane & 15, fq = lane >> 4;
   int buf = 0, kt = 0, ti = 0;
   f32x2 lnst[4] = {{0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}};
   for (int pc = 0; pc < P; ++pc) {
     // step pc landed (this wave's part); up to two younger steps (4 LDS-DMA pieces each) stay in flight
     const int younger = pp - pc - 1;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (WRING == 4) {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {  // two stages: only step pc itself was in flight
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // every wave's part landed; every wave is past step pc-1: its buffer is free
     PM_WSTAGE_NEXT();
     if (kt == nk - 1 && ln.stats) {
@@ -133,18 +144,19 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
       }
     }
     const char* xcur = smem + buf * WSTAGE;
-    const char* wcur = xcur + WBM * 64;
-    {
+    const char* wcur = xcur + WBM * WROWB;
+#pragma unroll
+    for (int ss = 0; ss < WBK / 32; ++ss) {
       bf16x8 a[8], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) b[i] = wread(xcur, wm * 64 + i * 16 + fr, fq);
+      for (int i = 0; i < 4; ++i) b[i] = wread(xcur, wm * 64 + i * 16 + fr, ss * 4 + fq);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = wread(wcur, wn * 128 + j * 16 + fr, fq);
+      for (int j = 0; j < 8; ++j) a[j] = wread(wcur, wn * 128 + j * 16 + fr, ss * 4 + fq);
       __builtin_amdgcn_sched_barrier(0);
 #if !PM_STATIC_PRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
-      if (kt == 0) {  // a tile's first step starts from the constant 0: nobody has to clear 128 accumulator registers
+      if (kt == 0 && ss == 0) {  // a tile's first step starts from the constant 0: nobody has to clear 128 accumulator registers
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j)
