@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
     const bf16* resid, int64_t ldr, int resid_period, bf16* Y, int64_t ldy, int M, int N, int K, int tiles_m, int tiles_n,
     int x_rows_per_batch, int64_t x_batch_stride, PmLnFold ln) {
-  __shared__ __attribute__((aligned(16))) char smem[WRING * WSTAGE];
+  __shared__ __attribute__((aligned(16))) char smem[WRING * WSTAGE + 8 * 4096];  // ring + 4 KiB of epilogue staging per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -182,8 +182,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
     wtile_coords(tbase + local + ti * nloc, tiles_m, tiles_n, tm, tn);
     ++ti;
     const int m0 = tm * WBM + wm * 64, n0 = tn * WBN + wn * 128;
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring buffer of this step: 4 KiB of it per wave
-    char* stg = smem + cbuf * WSTAGE + wave * 4096;
+    // every wave stages through its OWN 4 KiB behind the ring: no barrier in front of the epilogue, so a wave that
+    // finished its MFMAs early (waves 0-3 win the arbitration) converts and stores while its SIMD partner still computes
+    char* stg = smem + WRING * WSTAGE + wave * 4096;
     const int srow = lane >> 3, sch = lane & 7;
     // row-wise side: this lane stores rows m0 + srow + 8 k (k = 0..7), 8 features at n0 + 64 hf + 8 sch.  One 64-bit
     // multiply per tile; every other address is that base plus a wave-uniform offset (the per-store form cost ~10
