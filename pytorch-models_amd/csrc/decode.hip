@@ -423,15 +423,16 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 #endif
 constexpr int DF_THREADS = 512, DF_WAVES = 8;
 
-__device__ __forceinline__ float block_reduce8(float v, float* scratch, bool is_max) {
+// Block-wide sum / max over 8 waves through ONE barrier: every call site owns its 8-float slot of the scratch array, so
+// no barrier is needed to protect the slot's previous use (the kernel runs each reduction once).
+__device__ __forceinline__ float block_reduce8(float v, float* slot, bool is_max) {
   v = is_max ? wave_max(v) : wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) slot[wave] = v;
   __syncthreads();
-  if (lane == 0) scratch[wave] = v;
-  __syncthreads();
-  float r = scratch[0];
+  float r = slot[0];
 #pragma unroll
-  for (int w = 1; w < DF_WAVES; ++w) r = is_max ? fmaxf(r, scratch[w]) : r + scratch[w];
+  for (int w = 1; w < DF_WAVES; ++w) r = is_max ? fmaxf(r, slot[w]) : r + slot[w];
   return r;
 }
 
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   __shared__ float sc[DA_MAXK];
   __shared__ float xn[1280];
   __shared__ float qkv[192];
-  __shared__ float scratch[DF_WAVES];
+  __shared__ float scratch[4 * DF_WAVES];  // one slot per reduction: mean, variance, max, sum
   __shared__ float part[DF_WAVES * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     const int k = tid + i * DF_THREADS;
     if (k < d) q2 = fmaf(xe[i] - mean, xe[i] - mean, q2);
   }
-  const float rstd = rsqrtf(block_reduce8(q2, scratch, false) / (float)d + eps);
+  const float rstd = rsqrtf(block_reduce8(q2, scratch + DF_WAVES, false) / (float)d + eps);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int k = tid + i * DF_THREADS;
@@ -586,14 +587,14 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   __syncthreads();
   float mx = -INFINITY;
   for (int k = tid; k < Lk; k += DF_THREADS) mx = fmaxf(mx, sc[k]);
-  mx = block_reduce8(mx, scratch, true);
+  mx = block_reduce8(mx, scratch + 2 * DF_WAVES, true);
   float sum = 0.f;
   for (int k = tid; k < Lk; k += DF_THREADS) {
     const float p = expf(sc[k] - mx);
     sc[k] = p;
     sum += p;
   }
-  sum = block_reduce8(sum, scratch, false);  // its barriers also publish the p values
+  sum = block_reduce8(sum, scratch + 3 * DF_WAVES, false);  // its barrier also publishes the p values
 
   // ---- P.V
   float acc[8];
