@@ -12,7 +12,7 @@ from pytorch_models._hip import ops  # noqa: E402
 
 torch.manual_seed(0)
 B = 32
-for name, N, K, ks in (("out_proj", 512, 512, 0), ("fc1+ln+gelu", 2048, 512, 0), ("fc2 ksplit4", 512, 2048, 4), ("fc2 plain", 512, 2048, 0)):
+for name, N, K, ks in (("out_proj", 512, 512, 0), ("fc1+ln+gelu", 2048, 512, 0), ("fc2 plain", 512, 2048, 0)):
     NW = 64
     ws = [(torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16) for _ in range(NW)]
     x = torch.randn(B, K, device="cuda")
@@ -22,8 +22,6 @@ for name, N, K, ks in (("out_proj", 512, 512, 0), ("fc1+ln+gelu", 2048, 512, 0),
     junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 
     def call(w):
-        if ks:
-            return ops.dec_linear_ksplit(x, w, b, k_split=ks, resid=r)
         if name.startswith("fc1"):
             return ops.dec_linear(x, w, b, ln=(g, g, 1e-5), act="gelu")
         return ops.dec_linear(x, w, b, resid=r)
