@@ -16,6 +16,8 @@
 // rows are XOR-swizzled on the LDS-DMA source address (chunk c of row r at c ^ 3*((r >> 3) & 1): conflict-free for the
 // 16-row x 4-chunk fragment read); epilogue = bias / GELU in the accumulator layout, fp32 transposition of 16 x 64
 // blocks through the ring buffer the last step freed, residual + single rounding + 16-byte row-wise stores.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -273,5 +275,6 @@ bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act) {
   if (act != PM_ACT_NONE && act != PM_ACT_GELU) return false;
   if (K % WBK || N % 8) return false;
   const int64_t tiles = ((M + WBM - 1) / WBM) * ((N + WBN - 1) / WBN);
-  return M >= 4096 && tiles >= 1024;  // >= 4 tiles per persistent workgroup: the 256 x 256 tail stays below ~10 %
+  static const int64_t min_tiles = [] { const char* e = getenv("PM_WIDE_MIN_TILES"); return e ? atoll(e) : 1024LL; }();
+  return M >= 4096 && tiles >= min_tiles;  // >= 4 tiles per persistent workgroup: the 256 x 256 tail stays below ~10 %
 }

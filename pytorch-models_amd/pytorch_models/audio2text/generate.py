@@ -80,7 +80,7 @@ class GreedyDecoder:
 
         # plain projections with a long K (fc2: K = 4 d) are split over workgroups along K: see pm_dec_linear_ksplit
         ks_min = int(os.environ.get("PM_DEC_KSPLIT_MINK", "1024"))
-        self._ks_bufs = []
+        self._ks_bufs, self._ks_cnts = [], []
 
         def dec_linear_ks(x, K, w, bias, resid, out, N, act=0):
             ksp = int(os.environ.get("PM_DEC_KSPLIT", "4"))
@@ -90,6 +90,7 @@ class GreedyDecoder:
             ws = torch.empty(nt * ksp * mt * 256, **f32)
             cnt = torch.zeros(nt * 4, dtype=torch.int32, device=dev)  # one ticket per (feature tile, row tile)
             self._ks_bufs += [ws, cnt]
+            self._ks_cnts.append(cnt)
             self._keep += [w, bias]
             add(L.pm_dec_linear_ksplit, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _ptr(bias), _ptr(resid),
                 resid.stride(0) if resid is not None else 0, out.data_ptr(), out.stride(0), B, N, K, act, ksp,
@@ -200,6 +201,8 @@ class GreedyDecoder:
     def reset(self) -> None:
         self.pos.zero_()
         self.ticket.zero_()
+        for cnt in self._ks_cnts:  # the K-split tickets return to zero by themselves; this covers an aborted run
+            cnt.zero_()
         self.tok_cur.copy_(self.prompt[:, 0])
         fn, args = self._embed0  # x[b] = emb[prompt[b, 0]] + pos[0]
         check(fn(*args[:-1], torch.cuda.current_stream().cuda_stream), "pm_dec_embed")
