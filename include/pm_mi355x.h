@@ -207,6 +207,15 @@ int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_t
 /* ++*pos_ptr, as its own launch (every workgroup of the step has read t by then). */
 int pm_dec_advance(int32_t* pos_ptr, void* stream);
 
+/* Top-k sampling in place of the arg-max (text/generator.py:30-32: topk, softmax over the k logits, one multinomial draw):
+ * logits (B, V) f32, row stride ldl, of the last position (pm_dec_linear mode 0 with the final LayerNorm); per sequence the
+ * k (1..64) largest (ties: lowest index first), softmax over them, one draw from a counter-based generator keyed by
+ * (seed, position, sequence) - the same seed gives the same ids; then the tail of pm_dec_next_token (prompt forcing,
+ * x[b] = emb[token] + pos[t + 1], ticketed advance of *pos_ptr).  k = 1 is the arg-max. */
+int pm_dec_sample_topk(const float* logits, int64_t ldl, int64_t V, int64_t k, uint64_t seed, int32_t* pos_ptr,
+                       const int64_t* prompt, int64_t P, int64_t* tok_cur, int64_t* tokens_out, int64_t Ttot, const void* emb,
+                       const float* pos, float* x, int64_t d, int32_t* ticket, int64_t B, void* stream);
+
 /* pm_dec_argmax_reduce + the NEXT step's pm_dec_embed + pm_dec_advance in one launch (two launches fewer per decode
  * step): sequence b's workgroup picks its token as pm_dec_argmax_reduce does, writes x[b] = emb[token] + pos[t + 1], and
  * the last workgroup to finish - an agent-scope ticket in *ticket (int32, zero before the first launch, zero again after

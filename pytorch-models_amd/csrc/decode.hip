@@ -716,6 +716,101 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Top-k sampling of the next token (the reference's text/generator.py:30-32: topk, softmax over the k logits,
+// multinomial), one workgroup per sequence: k rounds of a block-wide arg-max in the order (value descending, index
+// ascending) - each round takes the best element that comes AFTER the previous winner in that order, so nothing is
+// masked or sorted - then a softmax over the k winners and one draw from a counter-based generator keyed by (seed,
+// position, sequence): the same seed gives the same text.  The tail is pm_dec_next_token's (prompt forcing, next
+// embedding row, ticketed position advance).
+constexpr int DS_MAXK = 64;
+
+__device__ __forceinline__ float ds_uniform(uint64_t seed, int t, int b) {  // splitmix64 finaliser -> [0, 1)
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(t + 1) + 0xBF58476D1CE4E5B9ull * (uint64_t)(b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void dec_sample_topk_kernel(const float* __restrict__ logits, int ldl, int V, int k,
+                                                              uint64_t seed, const int64_t* __restrict__ prompt, int P,
+                                                              int64_t* __restrict__ tok_cur, int64_t* __restrict__ tokens_out,
+                                                              int Ttot, const bf16* __restrict__ E,
+                                                              const float* __restrict__ pos_tab, float* __restrict__ x, int d,
+                                                              int* ticket, int* pos_rw) {
+  __shared__ float topv[DS_MAXK];
+  __shared__ int topi[DS_MAXK];
+  __shared__ float wv[4];
+  __shared__ int wi[4];
+  __shared__ int64_t snext;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (int64_t)b * ldl;
+  float pv = INFINITY;  // previous winner (value, index): the first round accepts everything
+  int pi = -1;
+  for (int r = 0; r < k; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      const float v = row[i];
+      const bool after = v < pv || (v == pv && i > pi);
+      if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { wv[wave] = bv; wi[wave] = bi; }
+    __syncthreads();
+    bv = wv[0];
+    bi = wi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (wv[w] > bv || (wv[w] == bv && wi[w] < bi)) { bv = wv[w]; bi = wi[w]; }
+    if (tid == 0) { topv[r] = bv; topi[r] = bi; }
+    pv = bv;
+    pi = bi;
+    __syncthreads();
+  }
+  const int t = *pos_rw;
+  if (tid == 0) {
+    float cum[DS_MAXK];
+    float sum = 0.f;
+    for (int r = 0; r < k; ++r) { sum += expf(topv[r] - topv[0]); cum[r] = sum; }
+    const float u = ds_uniform(seed, t, b) * sum;
+    int pick = k - 1;
+    for (int r = k - 1; r >= 0; --r)
+      if (u < cum[r]) pick = r;
+    const int64_t next = (t + 1 < P) ? prompt[(int64_t)b * P + t + 1] : (int64_t)topi[pick];
+    tok_cur[b] = next;
+    if (t + 1 < Ttot) tokens_out[(int64_t)b * Ttot + t + 1] = next;
+    snext = next;
+  }
+  __syncthreads();
+  const int t1 = t + 1;
+  int64_t id = snext;
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  for (int c = tid; c < d / 8; c += 256) {
+    const bf16x8 e = *(const bf16x8*)(E + id * d + c * 8);
+    const f32x4 p0 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8), p1 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8 + 4);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o0[i] = (float)e[i] + p0[i]; o1[i] = (float)e[4 + i] + p1[i]; }
+    *(f32x4*)(x + (int64_t)b * d + c * 8) = o0;
+    *(f32x4*)(x + (int64_t)b * d + c * 8 + 4) = o1;
+  }
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int n = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == (int)gridDim.x - 1) {
+      __hip_atomic_store(pos_rw, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __global__ void dec_advance_kernel(int* pos_ptr) { *pos_ptr += 1; }
 
 }  // namespace
@@ -960,6 +1055,25 @@ extern "C" int pm_dec_next_token(const float* ws_val, const int32_t* ws_idx, int
   hipLaunchKernelGGL(dec_argmax_reduce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, ws_val,
                      (const int*)ws_idx, (int)n_tiles, (const int*)pos_ptr, prompt, (int)P, tok_cur, tokens_out, (int)Ttot,
                      margin_out, (const bf16*)emb, pos, x, (int)d, (int)V, (int*)ticket, (int*)pos_ptr);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+/* Top-k sampling instead of the arg-max of pm_dec_next_token: logits (B, V) f32 (row stride ldl) of the last position ->
+ * the k (1..64) largest per row (ties: lowest index first), softmax over them, one draw per sequence from a
+ * counter-based generator keyed by (seed, position, sequence); then pm_dec_next_token's tail (prompt forcing, the next
+ * step's embedding row, ticketed position advance).  k = 1 is the arg-max. */
+extern "C" int pm_dec_sample_topk(const float* logits, int64_t ldl, int64_t V, int64_t k, uint64_t seed, int32_t* pos_ptr,
+                                  const int64_t* prompt, int64_t P, int64_t* tok_cur, int64_t* tokens_out, int64_t Ttot,
+                                  const void* emb, const float* pos, float* x, int64_t d, int32_t* ticket, int64_t B,
+                                  void* stream) {
+  if (!logits || !pos_ptr || !prompt || !tok_cur || !tokens_out || !emb || !pos || !x || !ticket) return PM_EINVAL;
+  if (V <= 0 || ldl < V || k < 1 || k > DS_MAXK || k > V || P <= 0 || B <= 0 || Ttot < P || d <= 0) return PM_EINVAL;
+  if (d % 8) return PM_EUNSUPPORTED;
+  if (((uintptr_t)emb | (uintptr_t)pos | (uintptr_t)x) & 15) return PM_EALIGN;
+  hipLaunchKernelGGL(dec_sample_topk_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, logits, (int)ldl, (int)V,
+                     (int)k, seed, prompt, (int)P, tok_cur, tokens_out, (int)Ttot, (const bf16*)emb, pos, x, (int)d,
+                     (int*)ticket, (int*)pos_ptr);
   PM_CHECK_LAUNCH();
   return PM_OK;
 }

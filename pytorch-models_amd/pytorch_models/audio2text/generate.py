@@ -26,7 +26,8 @@ def _ptr(t: Tensor | None):
 class GreedyDecoder:
     """State + launch list of the decode step for one (decoder, batch, memory length) geometry."""
 
-    def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False, fused: bool = True) -> None:
+    def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False, fused: bool = True,
+                 topk: int = 1, seed: int = 0) -> None:
         E = dec.token_embs.weight
         if E.dtype != torch.bfloat16 or not E.is_cuda:
             raise NotImplementedError("greedy decode: bf16 weights on a HIP device only (model.to(torch.bfloat16).cuda())")
@@ -165,11 +166,23 @@ class GreedyDecoder:
             dec_linear(self.h[:, :hid], hid, None, None, 0.0, mlp.linear2.weight, _f32(mlp.linear2, "b", mlp.linear2.bias),
                        self.x, self.x, d)
         g, b = _f32(dec.norm, "g", dec.norm.weight), _f32(dec.norm, "b", dec.norm.bias)
-        dec_linear(self.x, d, g, b, dec.norm.eps, E, None, None, None, V, mode=2, ldo=0)
-        # token choice + the next step's embedding row + position advance: one launch
-        add(L.pm_dec_next_token, self.ws_val.data_ptr(), self.ws_idx.data_ptr(), n_tiles, self.pos.data_ptr(),
-            self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot, _ptr(self.margins),
-            E.data_ptr(), pos_f32.data_ptr(), self.x.data_ptr(), d, V, self.ticket.data_ptr(), B, None)
+        if not 1 <= topk <= 64:
+            raise ValueError("greedy decode: topk must be in 1..64")
+        self.topk = topk
+        if topk == 1:
+            dec_linear(self.x, d, g, b, dec.norm.eps, E, None, None, None, V, mode=2, ldo=0)
+            # token choice + the next step's embedding row + position advance: one launch
+            add(L.pm_dec_next_token, self.ws_val.data_ptr(), self.ws_idx.data_ptr(), n_tiles, self.pos.data_ptr(),
+                self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot, _ptr(self.margins),
+                E.data_ptr(), pos_f32.data_ptr(), self.x.data_ptr(), d, V, self.ticket.data_ptr(), B, None)
+        else:  # top-k sampling on the device (text/generator.py:30-32): full logits of the last position, then the draw
+            if margins:
+                raise ValueError("greedy decode: margins are an arg-max diagnostic (topk == 1)")
+            self.logits = torch.empty(B, V, **f32)
+            dec_linear(self.x, d, g, b, dec.norm.eps, E, None, None, self.logits, V, mode=0)
+            add(L.pm_dec_sample_topk, self.logits.data_ptr(), self.logits.stride(0), V, topk, int(seed) & (2**64 - 1),
+                self.pos.data_ptr(), self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot,
+                E.data_ptr(), pos_f32.data_ptr(), self.x.data_ptr(), d, self.ticket.data_ptr(), B, None)
 
     def rebind(self, memory: Tensor, prompt: Tensor) -> None:
         """New clips, same geometry: re-project the cross K/V INTO the existing buffers and swap the prompt, so the
@@ -229,9 +242,10 @@ class GreedyDecoder:
 
 @torch.no_grad()
 def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: bool = True, margins: bool = False,
-                  fused: bool = True):
+                  fused: bool = True, topk: int = 1, seed: int = 0):
     """tokens (B, P + n_new) int64 [and per-position diagnostic margins].  fused=False uses the unfused
-    projection + attention launches (same arithmetic, 2 more launches per layer)."""
-    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused)
+    projection + attention launches (same arithmetic, 2 more launches per layer); topk > 1 samples each token from the
+    softmax over the k largest logits on the device (same seed -> same ids)."""
+    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused, topk, seed)
     toks = st.run(graph)
     return (toks, st.margins) if margins else toks

@@ -1,9 +1,9 @@
 """Text generation for decoder-only models: drop-in for /root/reference pytorch_models/text/generator.py
 (DecoderGenerator(model, tokenizer).generate(prompt, max_tokens, topk)).
 
-topk == 1 (greedy) on a pre-norm model (GPT-2) runs the KV-cached decode-step kernels of audio2text/generate.py - the
-reference re-runs the whole sequence for every new token (generator.py:24-25, O(T^2)); post-norm models (GPT) and
-top-k sampling re-run the HIP forward per token like the reference does.  The tokenizer is any object with
+A pre-norm model (GPT-2) runs the KV-cached decode-step kernels of audio2text/generate.py, greedy or with top-k
+sampling on the device (pm_dec_sample_topk) - the reference re-runs the whole sequence for every new token
+(generator.py:24-25, O(T^2)); post-norm models (GPT) re-run the HIP forward per token like the reference does.  The tokenizer is any object with
 ``encode(str) -> list[int]``, ``decode(list[int]) -> str`` and ``eos_token_id`` (no tokenizer ships with this build)."""
 from __future__ import annotations
 
@@ -18,15 +18,15 @@ class DecoderGenerator:
 
     @torch.inference_mode()
     def generate_ids(self, tokens: list[int], max_tokens: int = 100, topk: int = 1, eos_token_id: int | None = None,
-                     generator: torch.Generator | None = None) -> list[int]:
+                     generator: torch.Generator | None = None, seed: int = 0) -> list[int]:
         """Token-level form of generate(): prompt ids -> prompt + new ids, stopping after eos_token_id (kept, as the
         reference keeps it) or max_tokens new tokens."""
         device = next(self.model.parameters()).device
         tokens = list(tokens)
         n = len(tokens)
-        if topk == 1 and hasattr(self.model, "generate") and all(l.pre_norm for l in self.model.layers):
+        if topk <= 64 and hasattr(self.model, "generate") and all(l.pre_norm for l in self.model.layers):
             room = self.model.pos_embs.shape[0] - n
-            out = self.model.generate(torch.tensor([tokens], device=device), min(max_tokens, room))[0].tolist()
+            out = self.model.generate(torch.tensor([tokens], device=device), min(max_tokens, room), topk=topk, seed=seed)[0].tolist()
             new = out[n:]
             if eos_token_id is not None and eos_token_id in new:
                 new = new[: new.index(eos_token_id) + 1]

@@ -95,6 +95,69 @@ def test_gpt2_greedy_batch_sizes(B):
         m.generate(synth_tokens("text_tok_65", (65, 4), 2000, 81).cuda(), 2)
 
 
+def test_topk_sampling_kernel_distribution():
+    """pm_dec_sample_topk on synthetic logits: k = 1 is the arg-max (lowest index on ties); for k = 5 every draw is one of
+    the five largest, the same seed repeats, and over 4096 (seed, position, sequence) keys the empirical frequencies
+    follow softmax(top-5 logits) (total variation < 0.05)."""
+    from pytorch_models._hip import check, lib
+
+    B, V, d, k = 32, 1000, 64, 5
+    gen = torch.Generator().manual_seed(3)
+    logits = torch.randn(B, V, generator=gen) * 2
+    logits[:, 7] = logits[:, 3]  # exact ties
+    dev = dict(device="cuda")
+    lg = logits.cuda()
+    E = torch.zeros(V, d, dtype=torch.bfloat16, **dev)
+    pos_tab = torch.zeros(8, d, dtype=torch.float32, **dev)
+    x = torch.empty(B, d, dtype=torch.float32, **dev)
+    prompt = torch.zeros(B, 1, dtype=torch.int64, **dev)
+    tok_cur = torch.zeros(B, dtype=torch.int64, **dev)
+    tokens = torch.zeros(B, 4, dtype=torch.int64, **dev)
+    pos = torch.zeros(1, dtype=torch.int32, **dev)
+    ticket = torch.zeros(1, dtype=torch.int32, **dev)
+
+    def draw(kk, seed):
+        pos.zero_()
+        check(lib().pm_dec_sample_topk(lg.data_ptr(), V, V, kk, seed, pos.data_ptr(), prompt.data_ptr(), 1, tok_cur.data_ptr(),
+                                       tokens.data_ptr(), 4, E.data_ptr(), pos_tab.data_ptr(), x.data_ptr(), d, ticket.data_ptr(),
+                                       B, None), "pm_dec_sample_topk")
+        assert int(pos) == 1 and int(ticket) == 0
+        return tok_cur.cpu().clone()
+
+    assert torch.equal(draw(1, 0), logits.argmax(-1))
+    top = logits.topk(k, -1)
+    counts = torch.zeros(B, k)
+    first = draw(k, 11)
+    assert torch.equal(draw(k, 11), first)
+    for seed in range(128):
+        t = draw(k, seed)
+        hit = t[:, None] == top.indices
+        assert hit.any(1).all()
+        counts += hit.float()
+    want = top.values.softmax(-1)
+    tv = 0.5 * (counts / 128 - want).abs().sum(1)
+    assert float(counts.sum()) == B * 128 and float(tv.mean()) < 0.08, tv
+
+
+def test_gpt2_topk_sampling_stays_inside_the_oracle_top_k():
+    """GPT2.generate(topk = 4): repeatable for a seed, different seeds differ, and every sampled token is one of the four
+    most likely continuations of its prefix according to the fp32 oracle (near-ties at the boundary excepted)."""
+    from pytorch_models.text import GPT2
+
+    m, sd = prep(GPT2(2, 128), 72)
+    tok = synth_tokens("text_tok", (2, 16), 2000, 71)
+    P, n_new, k = 6, 16, 4
+    a = m.generate(tok[:, :P].cuda(), n_new, topk=k, seed=5).cpu()
+    assert torch.equal(m.generate(tok[:, :P].cuda(), n_new, topk=k, seed=5).cpu(), a)
+    assert not torch.equal(m.generate(tok[:, :P].cuda(), n_new, topk=k, seed=6).cpu(), a)
+    lg = RX.gpt2(sd, a[:, :-1])  # oracle logits for every prefix of the sampled text
+    for b in range(2):
+        for t in range(P, P + n_new):
+            row = lg[b, t - 1]
+            kth = row.topk(k).values[-1]
+            assert row[a[b, t]] >= kth - 2e-3, (b, t)
+
+
 def test_gpt2_size_geometry_runs_one_step():
     """GPT-2 small geometry (12 x 768, 12 heads), batch 4: logits shape / finiteness and 8 greedy tokens in range."""
     from pytorch_models.text import GPT2
