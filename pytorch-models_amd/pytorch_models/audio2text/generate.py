@@ -67,7 +67,10 @@ class GreedyDecoder:
         self.tokens[:, :P] = self.prompt
         self.margins = torch.zeros(B, self.Ttot, **f32) if margins else None
         L = lib()
-        tile = L.pm_dec_argmax_tile(d)
+        # d_model > 512: the final LayerNorm runs once as its own launch and the vocabulary projection without the
+        # in-kernel LayerNorm, whose register budget would halve the feature tile (GPT-2 small: 101 -> ~55 us per step)
+        self.split_final_norm = (d // 32 + 3) // 4 > 4
+        tile = 64 if self.split_final_norm else L.pm_dec_argmax_tile(d)
         n_tiles = (V + tile - 1) // tile  # pm_dec_linear mode 2 leaves one (max, index) per tile and sequence
         self.ws_val = torch.empty(B, n_tiles, **f32)
         self.ws_idx = torch.empty(B, n_tiles, dtype=torch.int32, device=dev)
@@ -98,7 +101,7 @@ class GreedyDecoder:
                 ws.data_ptr(), cnt.data_ptr(), None)
 
         def dec_linear(x, K, gamma, beta, eps, w, bias, resid, out, N, act=0, mode=0, kc=None, vc=None, ldo=None):
-            if mode == 0 and gamma is None and K >= ks_min and int(os.environ.get("PM_DEC_KSPLIT", "4")) > 1:
+            if mode == 0 and gamma is None and K >= ks_min and N <= 4096 and int(os.environ.get("PM_DEC_KSPLIT", "4")) > 1:
                 return dec_linear_ks(x, K, w, bias, resid, out, N, act)
             self._keep += [w, bias, gamma, beta]
             add(L.pm_dec_linear, x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), w.data_ptr(), w.stride(0),
@@ -124,7 +127,12 @@ class GreedyDecoder:
             wqkv, bqkv = sa._pack("qkv")
             g, b = _f32(layer.sa_norm, "g", layer.sa_norm.weight), _f32(layer.sa_norm, "b", layer.sa_norm.bias)
             self._keep += [wqkv, bqkv, g, b]
-            fuse_self = fused and os.environ.get("PM_DEC_FUSE_SELF", "1") != "0"
+            # the fused self block is one 512-thread workgroup per (sequence, head) that pulls the head's q/k/v weights
+            # (3 * 64 * d * 2 B) through its CU: it wins while every workgroup has a CU to itself (B * H <= 256 on MI355X:
+            # Whisper-base b = 32), beyond that the row-split projection + attention pair is faster (GPT-2 small b = 32,
+            # B * H = 384: 705 -> 641 us per step)
+            env_fs = os.environ.get("PM_DEC_FUSE_SELF")
+            fuse_self = fused and (B * H <= 256 if env_fs is None else env_fs != "0")
             fuse_cross = fused and os.environ.get("PM_DEC_FUSE_CROSS", "1") != "0"
             if fuse_self:  # LN + q/k/v projection + cache append + attention in one launch per layer
                 add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
@@ -169,8 +177,15 @@ class GreedyDecoder:
         if not 1 <= topk <= 64:
             raise ValueError("greedy decode: topk must be in 1..64")
         self.topk = topk
+        xl, gl, bl = self.x, g, b
+        if self.split_final_norm:
+            self.xn = torch.empty(B, d, **f32)
+            self._keep += [g, b]
+            add(L.pm_layernorm, self.x.data_ptr(), d, 1, g.data_ptr(), b.data_ptr(), float(dec.norm.eps), self.xn.data_ptr(), d, 1,
+                B, d, None)
+            xl, gl, bl = self.xn, None, None
         if topk == 1:
-            dec_linear(self.x, d, g, b, dec.norm.eps, E, None, None, None, V, mode=2, ldo=0)
+            dec_linear(xl, d, gl, bl, dec.norm.eps, E, None, None, None, V, mode=2, ldo=0)
             # token choice + the next step's embedding row + position advance: one launch
             add(L.pm_dec_next_token, self.ws_val.data_ptr(), self.ws_idx.data_ptr(), n_tiles, self.pos.data_ptr(),
                 self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot, _ptr(self.margins),
@@ -179,7 +194,7 @@ class GreedyDecoder:
             if margins:
                 raise ValueError("greedy decode: margins are an arg-max diagnostic (topk == 1)")
             self.logits = torch.empty(B, V, **f32)
-            dec_linear(self.x, d, g, b, dec.norm.eps, E, None, None, self.logits, V, mode=0)
+            dec_linear(xl, d, gl, bl, dec.norm.eps, E, None, None, self.logits, V, mode=0)
             add(L.pm_dec_sample_topk, self.logits.data_ptr(), self.logits.stride(0), V, topk, int(seed) & (2**64 - 1),
                 self.pos.data_ptr(), self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot,
                 E.data_ptr(), pos_f32.data_ptr(), self.x.data_ptr(), d, self.ticket.data_ptr(), B, None)
