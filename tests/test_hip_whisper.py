@@ -139,3 +139,29 @@ def test_whisper_tiny_reference_test_shape(golden):
     assert rel_l2(logits[0, :, :128], g["tiny_logits_slice"]) < 3e-2
     want = RW.decoder(sd, "decoder.", toks, memory.float().cpu())  # same memory -> isolates the decoder
     assert rel_l2(logits, want) < 3e-2
+
+
+def test_whisper_128_mel_path_end_to_end():
+    """The large-v3 front end (128 mels, vocab 51866: whisper.py:81-83,140) at reduced depth: 1 s of audio ->
+    WhisperPreprocessor("large-v3") -> a 2-layer, d = 128 Whisper with n_mels = 128 -> encoder memory and 8 greedy ids,
+    against the oracle on the same bf16-rounded weights."""
+    from pytorch_models.audio2text import Whisper, WhisperPreprocessor
+
+    w, sd = hip_and_sd(Whisper(51866, 2, 128, n_mels=128), 57)
+    wave = synth_input("w_wave128", (2, 16000), 57, scale=0.1)
+    mel = WhisperPreprocessor("large-v3").cuda()(wave.cuda())
+    assert mel.shape == (2, 128, 100)
+    torch.testing.assert_close(mel.cpu(), RS.whisper_log_mel(wave, 128, "rfft"), rtol=1e-5, atol=3e-5)
+    memory = w.encoder(mel)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    assert memory.shape == (2, 50, 128) and rel_l2(memory, RW.encoder(enc_sd, "", mel.cpu())) < 2e-2
+    prompt = synth_tokens("w_prompt128", (2, 3), 51866, 57)
+    toks = w.decoder.generate(memory, prompt.cuda(), 8).cpu()
+
+    def kv_round(name, t):
+        return t.to(torch.bfloat16).float() if name == "kv" else t
+
+    want, margins = RW.greedy_cached(sd, "decoder.", prompt, memory.float().cpu(), 8, rp=kv_round)
+    for b in range(2):
+        diff = (toks[b] != want[b]).nonzero()
+        assert not len(diff) or float(margins[b, int(diff[0]) - 3]) < 2e-4
