@@ -1,0 +1,84 @@
+"""Randomised shape sweep of pm_linear_bf16 (all three kernels behind one dispatcher: 128x128, 256x128 persistent,
+256x256 persistent) and pm_attention_bf16 against fp32 torch on the same bf16 operands.  Seeded: the same 70 + 24
+cases every run.  Large cases are checked on a sample of rows."""
+import math
+import random
+
+import pytest
+import torch
+
+from oracle import ref_transformer as RT
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        kind = rng.random()
+        if kind < 0.35:  # small / ragged: the 128x128 kernel
+            M, N, K = rng.randint(1, 700), rng.choice([8, 24, 100, 132, 200, 333, 512, 1000]), 8 * rng.randint(1, 40)
+        elif kind < 0.7:  # the 256x128 persistent kernel (>= 512 tiles, M >= 4096)
+            N = rng.choice([128, 384, 512, 768, 1024])
+            M = rng.randint(512 * 256 * 128 // N // 1 + 1, 512 * 256 * 128 // N + 9000) if N < 1024 else rng.randint(20000, 40000)
+            K = 64 * rng.randint(1, 12)
+        else:  # the 256x256 persistent kernel (>= 1024 tiles)
+            N = rng.choice([1536, 2048, 2304, 3072, 1032])
+            M = 1024 * 256 * 256 // N + rng.randint(1, 9000)
+            K = 64 * rng.randint(1, 8)
+        act = rng.choice(["none", "none", "gelu", "relu", "silu", "approximate_gelu"])
+        resid = rng.choice([None, None, "bf16", "f32"])
+        odt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float32])
+        out.append((M, N, K, act, resid, odt, rng.random() < 0.7))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(70, 1234), ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}-{c[3]}-{c[4]}-{'f32' if c[5] == torch.float32 else 'bf16'}")
+def test_linear_random_shapes(case):
+    from pytorch_models._hip import ops
+
+    M, N, K, act, resid, odt, with_bias = case
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g) * 0.1 if with_bias else None
+    r = None
+    if resid:
+        r = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16 if resid == "bf16" else torch.float32)
+    got = ops.linear(x, w, b, act=act, resid=r, out_dtype=odt)
+    assert got.shape == (M, N) and got.dtype == odt and torch.isfinite(got.float()).all()
+    idx = torch.arange(M, device="cuda") if M <= 2048 else torch.cat([
+        torch.arange(0, 300, device="cuda"), torch.arange(M - 300, M, device="cuda"),
+        torch.randint(0, M, (600,), device="cuda", generator=g)])
+    want = x[idx].float() @ w.float().T
+    if b is not None:
+        want = want + b
+    if act != "none":
+        want = RT.activation(want.cpu(), act).cuda()
+    if r is not None:
+        want = want + r[idx].float()
+    tol = 1e-2 if odt == torch.bfloat16 else 2e-3
+    rms = want.square().mean().sqrt().item()
+    torch.testing.assert_close(got[idx].float(), want, rtol=tol, atol=tol * max(rms, 1e-3))
+
+
+def _attn_cases(n, seed):
+    rng = random.Random(seed)
+    return [(rng.randint(1, 6), rng.choice([1, 2, 3, 8]), rng.randint(1, 400), rng.randint(1, 400), rng.random() < 0.4) for _ in range(n)]
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", _attn_cases(24, 99))
+def test_attention_random_shapes(B, H, Lq, Lk, causal):
+    from pytorch_models._hip import ops
+
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + Lq * 7 + Lk)
+    q = torch.randn(B, Lq, H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    k = torch.randn(B, Lk, H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    v = torch.randn(B, Lk, H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    got = ops.attention(q, k, v, H, causal, None)
+    qh, kh, vh = (RT.split_heads(t.float().cpu(), H) for t in (q, k, v))
+    want = RT.merge_heads(RT.sdpa(qh, kh, vh, None, causal))
+    live = torch.ones(Lq, dtype=torch.bool)
+    torch.testing.assert_close(got.float().cpu()[:, live], want[:, live], rtol=2e-2, atol=2e-2)
