@@ -933,7 +933,7 @@ extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, 
   if (ldx < K || ldw < K || ldx % 4 || ldw % 8) return PM_EALIGN;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)split_ws) & 15) return PM_EALIGN;
   if (ldo < N || (resid && ldr < N)) return PM_EINVAL;
-  if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
+  if (act != PM_ACT_NONE && act != PM_ACT_GELU && act != PM_ACT_GELU_TANH) return PM_EUNSUPPORTED;
   const int nwg = (int)((N + DL_FEATS - 1) / DL_FEATS);
   int mt = (int)((M + 15) / 16);
   static const bool rowsplit = [] { const char* e = getenv("PM_DEC_ROWSPLIT"); return !e || atoi(e) != 0; }();
@@ -966,6 +966,9 @@ extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, 
   if (act == PM_ACT_GELU) {
     if (per_wave <= 4 || mt > 2) PM_DLK(PM_ACT_GELU, 4);
     else PM_DLK(PM_ACT_GELU, 8);
+  } else if (act == PM_ACT_GELU_TANH) {
+    if (per_wave <= 4 || mt > 2) PM_DLK(PM_ACT_GELU_TANH, 4);
+    else PM_DLK(PM_ACT_GELU_TANH, 8);
   } else {
     if (per_wave <= 4 || mt > 2) PM_DLK(PM_ACT_NONE, 4);
     else PM_DLK(PM_ACT_NONE, 8);

@@ -82,3 +82,44 @@ def test_attention_random_shapes(B, H, Lq, Lk, causal):
     want = RT.merge_heads(RT.sdpa(qh, kh, vh, None, causal))
     live = torch.ones(Lq, dtype=torch.bool)
     torch.testing.assert_close(got.float().cpu()[:, live], want[:, live], rtol=2e-2, atol=2e-2)
+
+
+def _dec_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        M = rng.choice([1, 2, 7, 16, 17, 31, 32, 33, 48, 64])
+        K = 32 * rng.randint(1, 64)
+        N = rng.choice([16, 48, 100, 512, 640, 1536, 2048])
+        ln = K <= 1280 and (M <= 32 or K <= 512) and rng.random() < 0.5
+        ks = rng.choice([0, 0, 2, 3, 4, 8]) if not ln and K // 32 >= 8 else 0
+        out.append((M, N, K, ln, ks, rng.choice(["none", "gelu", "approximate_gelu"]), rng.random() < 0.5))
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,ln,ks,act,with_resid", _dec_cases(40, 7))
+def test_dec_linear_random_shapes(M, N, K, ln, ks, act, with_resid):
+    """pm_dec_linear / pm_dec_linear_ksplit (row tiles and K parts on separate workgroups) stay fp32-exact."""
+    from pytorch_models._hip import ops
+
+    g = torch.Generator().manual_seed(M + 31 * N + 977 * K)
+    x = torch.randn(M, K, generator=g) * 2
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if with_resid else None
+    xin = x.double()
+    lnp = None
+    if ln:
+        gam, bet = torch.randn(K, generator=g) * 0.1 + 1, torch.randn(K, generator=g) * 0.1
+        xin = RT.layernorm({"weight": gam.double(), "bias": bet.double()}, "", xin, 1e-5)
+        lnp = (gam.cuda(), bet.cuda(), 1e-5)
+    want = xin @ w.double().T + b.double()
+    if act != "none":
+        want = RT.activation(want, act)
+    if r is not None:
+        want = want + r.double()
+    if ks:
+        got = ops.dec_linear_ksplit(x.cuda(), w.cuda(), b.cuda(), k_split=ks, act=act, resid=r.cuda() if r is not None else None)
+    else:
+        got = ops.dec_linear(x.cuda(), w.cuda(), b.cuda(), ln=lnp, act=act, resid=r.cuda() if r is not None else None)
+    torch.testing.assert_close(got.cpu().double(), want, rtol=2e-5, atol=2e-5)
