@@ -123,3 +123,26 @@ def test_dec_linear_random_shapes(M, N, K, ln, ks, act, with_resid):
     else:
         got = ops.dec_linear(x.cuda(), w.cuda(), b.cuda(), ln=lnp, act=act, resid=r.cuda() if r is not None else None)
     torch.testing.assert_close(got.cpu().double(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("d,L,B,seed", [(128, 700, 190, 1), (256, 333, 200, 2), (384, 197, 230, 3), (512, 1500, 24, 4), (768, 197, 256, 5)])
+def test_encoder_layernorm_fold_random_geometries(d, L, B, seed):
+    """Encoder stacks at sizes where the LayerNorm fold engages (or, for small tile counts, does not): the chained
+    forward agrees with running the layers one by one, and a permuted batch gives the permuted output bit for bit."""
+    from pytorch_models.transformer import Encoder
+    from synthweights import bf16_round_, fill_module
+
+    m = Encoder(2, d, n_heads=d // 64, norm_eps=1e-6)
+    fill_module(m, 40 + seed)
+    bf16_round_(m)
+    m = m.to(torch.bfloat16).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(B, L, d, device="cuda", generator=g).to(torch.bfloat16)
+    got = m(x)
+    step = x
+    for layer in m:
+        step = layer(step)
+    rel = ((got.float() - step.float()).norm() / step.float().norm()).item()
+    assert rel < 1e-2 and torch.isfinite(got.float()).all(), rel
+    perm = torch.randperm(B, device="cuda", generator=g)
+    torch.testing.assert_close(m(x[perm]), got[perm], rtol=0, atol=0)
