@@ -12,7 +12,7 @@ from torch import Tensor, nn
 
 from .._hip import ops
 from ..audio.spectrogram import MelSpectrogram
-from ..transformer import Decoder, Encoder, LayerNorm, _f32, derived
+from ..transformer import Decoder, Encoder, LayerNorm, _f32, _wb, derived
 
 _SIZES = {  # tag -> (n_layers, d_model); "base" is 8 layers exactly as the reference builds it
     "tiny": (4, 384), "tiny.en": (4, 384), "base": (8, 512), "base.en": (8, 512),
@@ -53,9 +53,7 @@ class WhisperEncoder(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         """(B, n_mels, T) -> (B, T // 2, d): conv stem (both convs as MFMA GEMMs with fused GELU, the second
         also adding pos_embs in its epilogue), Encoder, LayerNorm."""
-        if self.stem[0].weight.dtype != torch.bfloat16:
-            raise NotImplementedError("WhisperEncoder: only the bf16 path is built; use model.to(torch.bfloat16)")
-        w1, b1, w2, b2 = self._stem_weights()
+        w1, b1, w2, b2 = self._stem_weights()  # bf16 copies whatever the parameters' dtype
         B, _, T = x.shape
         d = w2.shape[0]
         y1 = ops.whisper_stem1(x.float().contiguous(), w1, b1)  # (B, T + 2, d) bf16, rows 0 and T + 1 zero
@@ -64,7 +62,7 @@ class WhisperEncoder(nn.Module):
         # Conv1d(d, d, 3, stride 2, pad 1): output row t' reads buffer rows 2t', 2t'+1, 2t'+2 = 3*d contiguous values
         y2 = ops.linear_strided(y1, M=B * L, K=3 * d, row_stride=2 * d, rows_per_batch=L, batch_stride=(T + 2) * d,
                                 w=w2, bias=b2, act="gelu", resid=pos, resid_period=L)
-        return self.norm(self.layers(y2.view(B, L, d)))
+        return self.norm(self.layers(y2.view(B, L, d)), self.stem[0].weight.dtype)  # fp32 model -> fp32 memory
 
 
 class WhisperDecoder(nn.Module):
@@ -79,9 +77,7 @@ class WhisperDecoder(nn.Module):
 
     def forward(self, x: Tensor, memory: Tensor) -> Tensor:
         """tokens (B, L) int64, memory (B, S, d) -> logits (B, L, V) (tied embeddings), teacher-forced."""
-        E = self.token_embs.weight
-        if E.dtype != torch.bfloat16:
-            raise NotImplementedError("WhisperDecoder: only the bf16 path is built; use model.to(torch.bfloat16)")
+        E = _wb(self.token_embs, "E", self.token_embs.weight)
         h = ops.embed_tokens(x, E, _f32(self, "pos", self.pos_embs))  # (B, L, d) bf16
         h = self.norm(self.layers(h, memory))
         return ops.linear(h.view(-1, h.shape[-1]), E, None, out_dtype=torch.float32).view(*x.shape, E.shape[0])

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .._hip import ops
-from ..transformer import MHA, MLP, Encoder, LayerNorm, _f32, _fused_mlp, derived
+from ..transformer import MHA, MLP, Encoder, LayerNorm, _f32, _fused_mlp, _wb, derived
 
 
 class ClassTokenPooling(nn.Module):
@@ -76,9 +76,7 @@ class ViT(nn.Module):
 
     def tokens(self, imgs: Tensor) -> Tensor:
         """(N, 3, H, W) f32 -> (N, L [+1], d) bf16: patch projection + pe (+ cls) in one kernel."""
-        pw = self.patch_embed.weight
-        if pw.dtype != torch.bfloat16:
-            raise NotImplementedError(f"ViT: only the bf16 path is built (weights are {pw.dtype}); use model.to(torch.bfloat16)")
+        pw = _wb(self.patch_embed, "w", self.patch_embed.weight)  # an fp32 model runs through a cached bf16 copy
         if pw.shape[2] == 16:
             w2d = pw.view(pw.shape[0], -1)
         else:  # other patch sizes: K = 3*P*P zero-padded to a multiple of 64 (derived copy)
@@ -95,10 +93,11 @@ class ViT(nn.Module):
 
     def forward(self, imgs: Tensor) -> Tensor:
         out = self.layers(self.tokens(imgs))
+        io = self.patch_embed.weight.dtype  # bf16 model -> bf16 features, fp32 model -> fp32 features
         if isinstance(self.pooler, ClassTokenPooling):
             # LayerNorm is row-wise, so normalising only the pooled row equals norm-then-pool (vit.py:83-84)
-            return self.norm(out[:, 0])
-        return self.pooler(self.norm(out))
+            return self.norm(out[:, 0], io)
+        return self.pooler(self.norm(out)).to(io)
 
     @torch.no_grad()
     def resize_pe(self, size: int, interpolation_mode: str = "bicubic") -> None:

@@ -9,7 +9,7 @@ import torch
 from torch import Tensor, nn
 
 from .._hip import ops
-from ..transformer import Encoder, LayerNorm, _f32
+from ..transformer import Encoder, LayerNorm, _f32, _wb
 
 
 class BERT(nn.Module):
@@ -24,13 +24,11 @@ class BERT(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         """token ids (..., L) int64 -> hidden states (..., L, d) bf16 (bert.py:35-40)."""
-        E = self.token_embs.weight
-        if E.dtype != torch.bfloat16:
-            raise NotImplementedError("BERT: only the bf16 path is built; use model.to(torch.bfloat16)")
+        E = _wb(self.token_embs, "E", self.token_embs.weight)
         lead = x.shape
         h = ops.embed_tokens(x.reshape(-1, lead[-1]), E, _f32(self, "pos", self.pos_embs))
         h = self.layers(self.norm(h))
-        return h.view(*lead, h.shape[-1])
+        return h.view(*lead, h.shape[-1]).to(self.token_embs.weight.dtype)  # fp32 model -> fp32 hidden states
 
     @staticmethod
     def from_config(config: dict, **kwargs) -> "BERT":

@@ -10,15 +10,13 @@ import torch
 from torch import Tensor, nn
 
 from .._hip import ops
-from ..transformer import Decoder, LayerNorm, _f32
+from ..transformer import Decoder, LayerNorm, _f32, _wb
 
 _SIZES = {"gpt2": (12, 768), "gpt2-medium": (24, 1024), "gpt2-large": (36, 1280), "gpt2-xl": (48, 1600)}
 
 
 def _lm_forward(m, tokens: Tensor, final_norm) -> Tensor:
-    E = m.token_embs.weight
-    if E.dtype != torch.bfloat16:
-        raise NotImplementedError(f"{type(m).__name__}: only the bf16 path is built; use model.to(torch.bfloat16)")
+    E = _wb(m.token_embs, "E", m.token_embs.weight)  # an fp32 model runs through a cached bf16 copy of its weights
     lead = tokens.shape
     tok2 = tokens.reshape(-1, lead[-1])  # the reference also accepts an unbatched (L,) sequence (generator.py:25)
     h = ops.embed_tokens(tok2, E, _f32(m, "pos", m.pos_embs))

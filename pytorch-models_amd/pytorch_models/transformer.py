@@ -12,8 +12,11 @@ forward is a short sequence of hand-written gfx950 kernels reached through the C
     linear1 + GELU       -> pm_linear_bf16 with the activation in its epilogue
     linear2 + residual   -> pm_linear_bf16 with the residual add in its epilogue
 
-There is no CPU or eager fallback: tensors must live on a HIP device and the modules must be cast to
-bfloat16 (``model.to(torch.bfloat16).cuda()``); anything the kernels do not cover raises.
+There is no CPU or eager fallback: tensors must live on a HIP device; anything the kernels do not cover raises.
+The kernels compute in bf16 with fp32 accumulation.  ``model.to(torch.bfloat16)`` is the native form (bf16 activations
+end to end).  A model left in the reference's default fp32 still runs: its weights are used through cached bf16 copies,
+fp32 inputs are rounded to bf16 on the way in and every module returns the dtype it was given (fp32 residual stream) -
+same kernels, same bf16 tensor-core arithmetic, fp32 at the interface.
 """
 from __future__ import annotations
 
@@ -55,14 +58,32 @@ def _f32(module: nn.Module, key: str, t: Tensor | None) -> Tensor | None:
     return derived(module, key, (t,), lambda: t.detach().float().contiguous())
 
 
+_FLOATS = (torch.bfloat16, torch.float32)
+
+
 def _require_bf16(x: Tensor, w: Tensor, who: str) -> None:
+    """Device and dtype gate of every block: HIP tensors, bf16 or fp32 (fp32 is computed through bf16, see above)."""
     if not x.is_cuda or not w.is_cuda:
         raise RuntimeError(
             f"{who}: the MI355X build of pytorch_models runs on HIP devices only (input on {x.device}, weights on "
             f"{w.device}); there is no CPU path.")
-    if w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
-        raise NotImplementedError(
-            f"{who}: only the bf16 path is built (weights {w.dtype}, input {x.dtype}); use model.to(torch.bfloat16)")
+    if w.dtype not in _FLOATS or x.dtype not in _FLOATS:
+        raise NotImplementedError(f"{who}: bf16 or fp32 only (weights {w.dtype}, input {x.dtype})")
+
+
+def _wb(module: nn.Module, key: str, p: Tensor) -> Tensor:
+    """The parameter itself if it is bf16, else a cached bf16 copy (rebuilt when the parameter changes)."""
+    if p.dtype == torch.bfloat16:
+        return p
+    return derived(module, key + ":bf16", (p,), lambda: p.detach().to(torch.bfloat16).contiguous())
+
+
+def _xb(x: Tensor) -> Tensor:
+    return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+
+
+def _like(y: Tensor, ref_dtype: torch.dtype) -> Tensor:
+    return y if y.dtype == ref_dtype else y.to(ref_dtype)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -82,7 +103,7 @@ class Linear(nn.Linear):
 
     def forward(self, x: Tensor) -> Tensor:
         _require_bf16(x, self.weight, "Linear")
-        y = ops.linear(x.reshape(-1, x.shape[-1]), self.weight, _f32(self, "b", self.bias))
+        y = ops.linear(_xb(x).reshape(-1, x.shape[-1]), _wb(self, "w", self.weight), _f32(self, "b", self.bias), out_dtype=x.dtype)
         return y.view(*x.shape[:-1], self.out_features)
 
 
@@ -118,7 +139,7 @@ class MHA(nn.Module):
         params = [m.weight for m in mods] + [m.bias for m in mods]
 
         def build():
-            w = torch.cat([m.weight.detach() for m in mods], 0).contiguous()
+            w = torch.cat([m.weight.detach() for m in mods], 0).to(torch.bfloat16).contiguous()
             b = None if mods[0].bias is None else torch.cat([m.bias.detach().float() for m in mods], 0).contiguous()
             return w, b
 
@@ -149,6 +170,10 @@ class MHA(nn.Module):
             raise NotImplementedError("MHA: inference only (attention dropout is not implemented)")
         H, inner = self.n_heads, self.n_heads * self.head_dim
         Lq = q.shape[-2]
+        io_dtype = q.dtype
+        q = _xb(q)
+        k = None if k is None else _xb(k)
+        v = None if v is None else _xb(v)
         if k is None and v is None:  # self-attention: one projection over the concatenated q/k/v weight
             lead = q.shape[:-2]
             w, b = self._pack("qkv")
@@ -185,7 +210,8 @@ class MHA(nn.Module):
                 bias4 = bias4.contiguous()
         o = ops.attention(qh, kh, vh, H, causal, bias4)
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
-        y = ops.linear(o.view(-1, inner), self.out_proj.weight, _f32(self.out_proj, "b", self.out_proj.bias), resid=res2)
+        y = ops.linear(o.view(-1, inner), _wb(self.out_proj, "w", self.out_proj.weight), _f32(self.out_proj, "b", self.out_proj.bias),
+                       resid=res2, out_dtype=io_dtype)
         return y.view(*lead, Lq, y.shape[-1])
 
 
@@ -217,10 +243,11 @@ class MLP(nn.Module):
         _require_bf16(x, self.linear1.weight, "MLP")
         if self.training and self.dropout.p > 0.0:
             raise NotImplementedError("MLP: inference only (dropout is not implemented)")
-        x2 = x.reshape(-1, x.shape[-1])
-        h = ops.linear(x2, self.linear1.weight, _f32(self.linear1, "b", self.linear1.bias), act=self.act_name)
+        x2 = _xb(x).reshape(-1, x.shape[-1])
+        h = ops.linear(x2, _wb(self.linear1, "w", self.linear1.weight), _f32(self.linear1, "b", self.linear1.bias), act=self.act_name)
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
-        y = ops.linear(h, self.linear2.weight, _f32(self.linear2, "b", self.linear2.bias), resid=res2)
+        y = ops.linear(h, _wb(self.linear2, "w", self.linear2.weight), _f32(self.linear2, "b", self.linear2.bias), resid=res2,
+                       out_dtype=x.dtype)
         return y.view(*x.shape)
 
 

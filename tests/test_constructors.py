@@ -97,8 +97,8 @@ def test_state_dict_roundtrip_and_derived_cache_invalidation():
     m = MHA(64, n_heads=1)
     sd = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
     m.load_state_dict(sd)
-    w1, _ = m._pack("qkv")
-    assert torch.equal(w1[:64], sd["q_proj.weight"]) and w1.shape == (192, 64)
+    w1, _ = m._pack("qkv")  # the packed projection is always bf16 (an fp32 model runs through bf16 copies of its weights)
+    assert w1.dtype == torch.bfloat16 and torch.equal(w1[:64], sd["q_proj.weight"].to(torch.bfloat16)) and w1.shape == (192, 64)
     assert m._pack("qkv")[0] is w1  # cached
     with torch.no_grad():
         m.k_proj.weight.copy_(torch.zeros(64, 64))  # in-place load (what the converters do) must invalidate

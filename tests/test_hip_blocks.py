@@ -187,5 +187,5 @@ def test_uncovered_configurations_raise_instead_of_falling_back():
     x = torch.zeros(1, 4, 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(NotImplementedError, match="head_dim"):
         MHA(64, n_heads=16).to(torch.bfloat16).cuda()(x)  # head_dim 4
-    with pytest.raises(NotImplementedError, match="bf16"):
-        MHA(64).cuda()(x.float())
+    with pytest.raises(NotImplementedError, match="bf16 or fp32"):
+        MHA(64).cuda().half()(x.half())
