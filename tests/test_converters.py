@@ -59,4 +59,6 @@ def test_openai_whisper_and_cache_invalidation():
     check(w, "openai_whisper")
     assert w.decoder.layers[0].sa.k_proj.bias.abs().sum() == 0  # OpenAI's key projection has no bias
     qkv_after, _ = w.decoder.layers[0].sa._pack("qkv")
-    assert qkv_after is not qkv_before and torch.equal(qkv_after[:64], w.decoder.layers[0].sa.q_proj.weight)
+    assert qkv_after is not qkv_before and torch.equal(
+        qkv_after[:64], w.decoder.layers[0].sa.q_proj.weight.to(torch.bfloat16)
+    )  # packed copies are bf16 whatever the module dtype
