@@ -74,6 +74,40 @@ int pm_linear_ln_supported(int64_t M, int64_t N, int64_t K, int act, int produce
 int pm_layernorm(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps,
                  void* y, int64_t ldy, int y_dtype, int64_t M, int64_t d, void* stream);
 
+/* pm_layernorm with the two things the audio encoders put right behind a norm fused in:
+ * y = act(LayerNorm(x)) + resid.  gamma and beta both NULL = no affine (LayerNorm1d(elementwise_affine=False),
+ * audio/data2vec_audio.py:27); act: PM_ACT_NONE | PM_ACT_GELU (erff; audio/wav2vec2.py:38 norm -> GELU);
+ * resid: NULL or resid_dtype (M, d) with row stride ldr. */
+int pm_layernorm_ex(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps, int act,
+                    const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype, int64_t M,
+                    int64_t d, void* stream);
+
+/* ---- Wav2Vec2 / Data2VecAudio / SEW (audio/wav2vec2.py, audio/data2vec_audio.py, audio/sew.py).
+ * All feature-encoder activations are (clip, time, channel) bf16, so Conv1d(C, C', k, stride s) over them is
+ * pm_linear_bf16_ex with row stride s*C and K = k*C (weight K order (tap, channel)).
+ *
+ * Layer 0 (audio/wav2vec2.py:32-38 with in_dim 1): out[b, t, c] = GELU(norm(bias[c] + sum_j w[c, j] x[b, t*stride + j])),
+ * T0 = (L - k) / stride + 1.  x: f32 (B, L); w: f32 (C0, k) = the Conv1d weight as stored; bias: f32 (C0) or NULL;
+ * out: bf16 (B, T0, C0).  norm: PM_W2V_NORM_NONE | PM_W2V_NORM_LAYER (LayerNorm1d over channels, gamma / beta f32 (C0)) |
+ * PM_W2V_NORM_INSTANCE (InstanceNorm1d(affine) over time per clip and channel: two passes over the waveform, scratch
+ * partials f32 (B, pm_w2v_stem0_chunks(T0), C0, 2) and stats f32 (B, C0, 2) supplied by the caller; fixed reduction
+ * order).  k == 10, C0 % 8 == 0, C0 <= 512. */
+enum { PM_W2V_NORM_NONE = 0, PM_W2V_NORM_LAYER = 1, PM_W2V_NORM_INSTANCE = 2 };
+int64_t pm_w2v_stem0_chunks(int64_t T0);
+int pm_w2v_stem0(const float* x, const float* w, const float* bias, int norm, const float* gamma, const float* beta, float eps,
+                 float* partials, float* stats, void* out, int64_t B, int64_t L, int64_t C0, int64_t k, int64_t stride,
+                 void* stream);
+
+/* Regrouping for the grouped positional conv (audio/wav2vec2.py:70-74: ConstantPad1d + Conv1d(d, d, k, groups=G)):
+ * out[b, g, pad_left + t, c] = bf16(x[b, t, g*cg + c]), zero in the pad rows and for c in [cg, cgp).  x: x_dtype
+ * (B, T, >= G*cg) with row stride ldx; out: bf16 (B, G, pad_left + T + pad_right, cgp), cgp % 8 == 0.  Group g's conv
+ * window at step t is then the k*cgp contiguous values at out[b, g, t*stride], i.e. one pm_linear_bf16_ex per group. */
+int pm_group_windows(const void* x, int64_t ldx, int x_dtype, void* out, int64_t B, int64_t T, int64_t G, int64_t cg,
+                     int64_t cgp, int64_t pad_left, int64_t pad_right, void* stream);
+
+/* F.avg_pool1d(x, 2) over time on (B, T, d) bf16 -> (B, T / 2, d) bf16 (audio/sew.py:33; a trailing odd row is dropped). */
+int pm_avgpool_time2(const void* x, void* out, int64_t B, int64_t T, int64_t d, void* stream);
+
 /* F.scaled_dot_product_attention (transformer.py:52) for head_dim 64, bf16 operands:
  * o[b,i,h,:] = softmax_j(q[b,i,h,:] . k[b,j,h,:] / 8 [j <= i if causal]) v[b,j,h,:].
  * q/k/v/o are addressed as base + b*stride_b + token*stride_t + h*64 (elements), so the packed

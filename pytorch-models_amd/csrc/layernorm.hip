@@ -42,7 +42,8 @@ __device__ __forceinline__ void store8(void* y, int64_t off, const float (&v)[8]
 template <bool XF32, bool YF32, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, void* __restrict__ y, int64_t ldy, int64_t M, int d) {
+                                                        float eps, void* __restrict__ y, int64_t ldy, int64_t M, int d,
+                                                        int act, const void* __restrict__ resid, int64_t ldr, int resid_f32) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -77,10 +78,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     const int ch = lane + c * 64;
     if (ch < nchunk) {
       float g[8], b[8];
-      load8<true>(gamma, ch * 8, g);
-      load8<true>(beta, ch * 8, b);
+      if (gamma) {  // elementwise_affine=False (data2vec_audio.py:27) passes null
+        load8<true>(gamma, ch * 8, g);
+        load8<true>(beta, ch * 8, b);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = fmaf(v[c][i] * rstd, g[i], b[i]);
+        for (int i = 0; i < 8; ++i) v[c][i] = fmaf(v[c][i] * rstd, g[i], b[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[c][i] *= rstd;
+      }
+      if (act == PM_ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[c][i] = apply_act<PM_ACT_GELU, true>(v[c][i]);
+      }
+      if (resid) {
+        if (resid_f32) load8<true>(resid, row * ldr + ch * 8, g);
+        else load8<false>(resid, row * ldr + ch * 8, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[c][i] += g[i];
+      }
       store8<YF32>(y, row * ldy + ch * 8, v[c]);
     }
   }
@@ -88,9 +104,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 
 template <bool XF32, bool YF32>
 void launch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t ldx, const float* g, const float* b, float eps,
-            void* y, int64_t ldy, int64_t M, int d) {
-#define PM_LN(N)                                                                                                  \
-  hipLaunchKernelGGL((layernorm_kernel<XF32, YF32, N>), grid, dim3(256), 0, st, x, ldx, g, b, eps, y, ldy, M, d); \
+            void* y, int64_t ldy, int64_t M, int d, int act, const void* resid, int64_t ldr, int resid_f32) {
+#define PM_LN(N)                                                                                                       \
+  hipLaunchKernelGGL((layernorm_kernel<XF32, YF32, N>), grid, dim3(256), 0, st, x, ldx, g, b, eps, y, ldy, M, d, act, \
+                     resid, ldr, resid_f32);                                                                           \
   break
   switch (nch) {
     case 1: PM_LN(1);
@@ -104,25 +121,36 @@ void launch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t ldx, cons
 
 }  // namespace
 
-extern "C" int pm_layernorm(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps,
-                            void* y, int64_t ldy, int y_dtype, int64_t M, int64_t d, void* stream) {
-  if (!x || !gamma || !beta || !y || M < 0 || d <= 0) return PM_EINVAL;
+// y = act(LayerNorm(x)) + resid; gamma / beta both null = no affine; act in {NONE, GELU}; resid null = none.
+extern "C" int pm_layernorm_ex(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps,
+                               int act, const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype,
+                               int64_t M, int64_t d, void* stream) {
+  if (!x || !y || M < 0 || d <= 0 || ((gamma == nullptr) != (beta == nullptr))) return PM_EINVAL;
   if ((x_dtype != PM_BF16 && x_dtype != PM_F32) || (y_dtype != PM_BF16 && y_dtype != PM_F32)) return PM_EINVAL;
+  if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
+  if (resid && resid_dtype != PM_BF16 && resid_dtype != PM_F32) return PM_EINVAL;
   if (M == 0) return PM_OK;
   if (d % 8 != 0 || d > MAX_CHUNKS * 512) return PM_EUNSUPPORTED;
-  if (ldx < d || ldy < d) return PM_EINVAL;
-  if (ldx % 8 || ldy % 8) return PM_EALIGN;
-  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return PM_EALIGN;
+  if (ldx < d || ldy < d || (resid && ldr < d)) return PM_EINVAL;
+  if (ldx % 8 || ldy % 8 || (resid && ldr % 8)) return PM_EALIGN;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)resid) & 15) return PM_EALIGN;
   const int64_t nblk = (M + 3) / 4;
   if (nblk > 0x7fffffff) return PM_EINVAL;
   const int nch = (int)((d / 8 + 63) / 64);
   dim3 grid((unsigned)nblk);
   hipStream_t st = (hipStream_t)stream;
   const bool xf = x_dtype == PM_F32, yf = y_dtype == PM_F32;
-  if (xf && yf) launch<true, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d);
-  else if (xf) launch<true, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d);
-  else if (yf) launch<false, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d);
-  else launch<false, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d);
+  const int rf = resid_dtype == PM_F32;
+  if (xf && yf) launch<true, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
+  else if (xf) launch<true, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
+  else if (yf) launch<false, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
+  else launch<false, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
   PM_CHECK_LAUNCH();
   return PM_OK;
+}
+
+extern "C" int pm_layernorm(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps,
+                            void* y, int64_t ldy, int y_dtype, int64_t M, int64_t d, void* stream) {
+  if (!gamma || !beta) return PM_EINVAL;
+  return pm_layernorm_ex(x, ldx, x_dtype, gamma, beta, eps, PM_ACT_NONE, nullptr, 0, PM_BF16, y, ldy, y_dtype, M, d, stream);
 }

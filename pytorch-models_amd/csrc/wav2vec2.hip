@@ -1,0 +1,278 @@
+// wav2vec2.hip - the pieces of Wav2Vec2 / Data2VecAudio / SEW that are not a plain GEMM, LayerNorm or attention:
+//   * layer 0 of the feature encoder: Conv1d(1, C0, k, stride) on the raw waveform, its norm and GELU, written
+//     TIME-major in bf16 (reference: pytorch_models/audio/wav2vec2.py:19-39,80: conv -> LayerNorm1d | InstanceNorm1d
+//     | Identity -> GELU);
+//   * the regrouping that turns the grouped positional conv (wav2vec2.py:70-74, data2vec_audio.py:23-30) into G
+//     K-contiguous GEMMs on linear_bf16.hip.
+//
+// Layout decision: every activation of the feature encoder is (clip, time, channel).  With K ordered (tap, channel)
+// the window of a Conv1d(C, C', k, stride s) at output step t is the k*C CONTIGUOUS values starting at row t*s, so
+// layers 1..6 are pm_linear_bf16_ex calls (row stride s*C, K = k*C) with GELU in the epilogue, and the channel
+// LayerNorm of the non-legacy stem is the row-wise pm_layernorm_ex - the transpose(1, 2) pairs of the reference never
+// happen.  Layer 0 has K = 10: no GEMM, a lane keeps the taps of its 8 channels in registers and a wave emits one
+// 1 KiB output row per step; HBM-bound on the output (2*C0 bytes per step; 32.8 MB per 10 s clip at C0 = 512).
+//
+// InstanceNorm1d (legacy stem: statistics over TIME per clip and channel) needs a global reduction before the first
+// output can be written.  The conv is recomputed instead of stored: pass 1 accumulates (sum, sum of squares) per
+// channel over 256-step chunks (fixed order, no atomics: bit-reproducible), a finalize kernel folds the chunks in fp64
+// into (mean, rstd), pass 2 recomputes the conv and writes the normalised activations.  10 FMAs per value twice is
+// cheaper than a 4-byte round trip.
+#include "common.h"
+
+namespace {
+
+constexpr int TCH = 256;  // time steps per workgroup = statistics chunk
+
+enum { MODE_NONE = 0, MODE_LAYERNORM = 1, MODE_INSTANCE = 2, MODE_STATS = 3 };
+
+template <int KT, int MODE>
+__global__ __launch_bounds__(256) void w2v_stem0_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ stats,
+                                                        float* __restrict__ partials, float eps, bf16* __restrict__ out,
+                                                        int64_t L, int T0, int C0, int stride, int nchunk) {
+  __shared__ float red[4][512][2];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int c0 = lane * 8;
+  const bool on = c0 < C0;  // C0 % 8 == 0: a lane's 8 channels are all inside or all outside
+  float wr[KT][8], bs[8], g[8], bt[8], mu[8], rs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = on ? c0 + i : 0;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) wr[j][i] = on ? w[c * KT + j] : 0.f;
+    bs[i] = (on && bias) ? bias[c] : 0.f;
+    g[i] = (on && gamma) ? gamma[c] : 1.f;
+    bt[i] = (on && beta) ? beta[c] : 0.f;
+    if constexpr (MODE == MODE_INSTANCE) {
+      mu[i] = stats[((int64_t)b * C0 + c) * 2];
+      rs[i] = stats[((int64_t)b * C0 + c) * 2 + 1];
+    }
+  }
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* xb = x + (int64_t)b * L;
+  const int t_end = min((chunk + 1) * TCH, T0);
+  const float inv_c = 1.0f / (float)C0;
+  for (int t = chunk * TCH + wave; t < t_end; t += 4) {
+    const float* xs = xb + (int64_t)t * stride;  // wave-uniform: the taps arrive by scalar loads
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = bs[i];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const float xv = xs[j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaf(wr[j][i], xv, v[i]);
+    }
+    if constexpr (MODE == MODE_STATS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s8[i] += v[i];
+        q8[i] = fmaf(v[i], v[i], q8[i]);
+      }
+      continue;
+    }
+    if constexpr (MODE == MODE_LAYERNORM) {  // over the C0 channels of this step (LayerNorm1d, wav2vec2.py:14-16)
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += on ? v[i] : 0.f;
+      const float mean = wave_sum(s) * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] -= mean;
+        q = on ? fmaf(v[i], v[i], q) : q;
+      }
+      const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i] * rstd, g[i], bt[i]);
+    }
+    if constexpr (MODE == MODE_INSTANCE) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaf((v[i] - mu[i]) * rs[i], g[i], bt[i]);
+    }
+    if (on) {
+      bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (bf16)apply_act<PM_ACT_GELU, true>(v[i]);
+      *(bf16x8*)(out + ((int64_t)b * T0 + t) * C0 + c0) = o;
+    }
+  }
+  if constexpr (MODE == MODE_STATS) {
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        red[wave][c0 + i][0] = s8[i];
+        red[wave][c0 + i][1] = q8[i];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C0; c += 256) {
+      const float s = ((red[0][c][0] + red[1][c][0]) + red[2][c][0]) + red[3][c][0];
+      const float q = ((red[0][c][1] + red[1][c][1]) + red[2][c][1]) + red[3][c][1];
+      float* p = partials + (((int64_t)b * nchunk + chunk) * C0 + c) * 2;
+      p[0] = s;
+      p[1] = q;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void w2v_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats,
+                                                                 int64_t BC, int C0, int nchunk, int T0, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BC) return;
+  const int64_t b = i / C0, c = i - b * C0;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const float* p = partials + ((b * nchunk + k) * C0 + c) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+  const double mean = s / T0;
+  const double var = fmax(q / T0 - mean * mean, 0.0);  // biased, like InstanceNorm1d
+  stats[i * 2] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// out[b][g][pl + t][c] = x[b][t][g*cg + c] (bf16), zero for the pl leading / pr trailing rows and for c in [cg, cgp)
+template <bool XF32>
+__global__ __launch_bounds__(256) void group_windows_kernel(const void* __restrict__ x, int64_t ldx, bf16* __restrict__ out,
+                                                            int T, int G, int cg, int cgp, int pl, int Tp, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 output channels
+  if (i >= total) return;
+  const int per_row = cgp >> 3;
+  const int ch = (int)(i % per_row);
+  int64_t r = i / per_row;
+  const int tp = (int)(r % Tp);
+  r /= Tp;
+  const int g = (int)(r % G);
+  const int64_t b = r / G;
+  const int t = tp - pl;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
+  if (t >= 0 && t < T) {
+    const int64_t src = (b * T + t) * ldx + (int64_t)g * cg;
+    if ((cg & 7) == 0) {
+      if constexpr (XF32) {
+        const f32x4 a = *(const f32x4*)((const float*)x + src + ch * 8), c = *(const f32x4*)((const float*)x + src + ch * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = (bf16)a[e]; o[4 + e] = (bf16)c[e]; }
+      } else {
+        o = *(const bf16x8*)((const bf16*)x + src + ch * 8);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = ch * 8 + e;
+        if (c < cg) o[e] = XF32 ? (bf16)((const float*)x)[src + c] : ((const bf16*)x)[src + c];
+      }
+    }
+  }
+  *(bf16x8*)(out + i * 8) = o;
+}
+
+// out[b][t][:] = (x[b][2t][:] + x[b][2t+1][:]) / 2 in fp32, rounded once (F.avg_pool1d(x, 2) over time, sew.py:33)
+__global__ __launch_bounds__(256) void avgpool_time2_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int T, int To, int d8,
+                                                            int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)(i % d8);
+  const int64_t r = i / d8;
+  const int t = (int)(r % To);
+  const int64_t b = r / To;
+  const bf16* p = x + ((b * T + 2 * t) * d8 + ch) * 8;
+  const bf16x8 a = *(const bf16x8*)p, c = *(const bf16x8*)(p + (int64_t)d8 * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)(0.5f * ((float)a[e] + (float)c[e]));
+  *(bf16x8*)(out + i * 8) = o;
+}
+
+template <int MODE>
+int launch_stem0(int k, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
+                 const float* beta, const float* stats, float* partials, float eps, bf16* out, int64_t L, int T0, int C0,
+                 int stride, int nchunk) {
+  if (k != 10) return PM_EUNSUPPORTED;  // every model of the family opens with Conv1d(1, C0, 10, 5)
+  hipLaunchKernelGGL((w2v_stem0_kernel<10, MODE>), grid, dim3(256), 0, st, x, w, bias, gamma, beta, stats, partials, eps, out, L,
+                     T0, C0, stride, nchunk);
+  return PM_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t pm_w2v_stem0_chunks(int64_t T0) { return (T0 + TCH - 1) / TCH; }
+
+extern "C" int pm_w2v_stem0(const float* x, const float* w, const float* bias, int norm, const float* gamma, const float* beta,
+                            float eps, float* partials, float* stats, void* out, int64_t B, int64_t L, int64_t C0, int64_t k,
+                            int64_t stride, void* stream) {
+  if (!x || !w || !out || B < 0 || L <= 0 || C0 <= 0 || k <= 0 || stride <= 0) return PM_EINVAL;
+  if (norm < PM_W2V_NORM_NONE || norm > PM_W2V_NORM_INSTANCE) return PM_EINVAL;
+  if (norm != PM_W2V_NORM_NONE && (!gamma || !beta)) return PM_EINVAL;
+  if (norm == PM_W2V_NORM_INSTANCE && (!partials || !stats)) return PM_EINVAL;
+  if (B == 0) return PM_OK;
+  if (L < k) return PM_EINVAL;
+  if (C0 % 8 || C0 > 512) return PM_EUNSUPPORTED;
+  if ((uintptr_t)out & 15) return PM_EALIGN;
+  const int64_t T0 = (L - k) / stride + 1;
+  const int64_t nchunk = (T0 + TCH - 1) / TCH;
+  if (T0 > 0x7fffffff / 8 || B > 65535) return PM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)nchunk, (unsigned)B);
+  int rc;
+  if (norm == PM_W2V_NORM_INSTANCE) {
+    rc = launch_stem0<MODE_STATS>((int)k, grid, st, x, w, bias, nullptr, nullptr, nullptr, partials, eps, nullptr, L, (int)T0,
+                                  (int)C0, (int)stride, (int)nchunk);
+    if (rc != PM_OK) return rc;
+    hipLaunchKernelGGL(w2v_stats_finalize_kernel, dim3((unsigned)((B * C0 + 255) / 256)), dim3(256), 0, st, partials, stats,
+                       B * C0, (int)C0, (int)nchunk, (int)T0, eps);
+    rc = launch_stem0<MODE_INSTANCE>((int)k, grid, st, x, w, bias, gamma, beta, stats, nullptr, eps, (bf16*)out, L, (int)T0,
+                                     (int)C0, (int)stride, (int)nchunk);
+  } else if (norm == PM_W2V_NORM_LAYER) {
+    rc = launch_stem0<MODE_LAYERNORM>((int)k, grid, st, x, w, bias, gamma, beta, nullptr, nullptr, eps, (bf16*)out, L, (int)T0,
+                                      (int)C0, (int)stride, (int)nchunk);
+  } else {
+    rc = launch_stem0<MODE_NONE>((int)k, grid, st, x, w, bias, nullptr, nullptr, nullptr, nullptr, eps, (bf16*)out, L, (int)T0,
+                                 (int)C0, (int)stride, (int)nchunk);
+  }
+  if (rc != PM_OK) return rc;
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+extern "C" int pm_group_windows(const void* x, int64_t ldx, int x_dtype, void* out, int64_t B, int64_t T, int64_t G, int64_t cg,
+                                int64_t cgp, int64_t pad_left, int64_t pad_right, void* stream) {
+  if (!x || !out || B < 0 || T <= 0 || G <= 0 || cg <= 0 || pad_left < 0 || pad_right < 0) return PM_EINVAL;
+  if (x_dtype != PM_BF16 && x_dtype != PM_F32) return PM_EINVAL;
+  if (cgp < cg || cgp % 8 || ldx < G * cg) return PM_EINVAL;
+  if (B == 0) return PM_OK;
+  if ((uintptr_t)out & 15) return PM_EALIGN;
+  if (cg % 8 == 0 && ((ldx % 8) || ((uintptr_t)x & 15))) return PM_EALIGN;
+  const int64_t Tp = T + pad_left + pad_right;
+  const int64_t total = B * G * Tp * (cgp / 8);
+  if (Tp > 0x7fffffff || (total + 255) / 256 > 0x7fffffff) return PM_EINVAL;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (x_dtype == PM_F32)
+    hipLaunchKernelGGL(group_windows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16*)out, (int)T, (int)G,
+                       (int)cg, (int)cgp, (int)pad_left, (int)Tp, total);
+  else
+    hipLaunchKernelGGL(group_windows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16*)out, (int)T, (int)G,
+                       (int)cg, (int)cgp, (int)pad_left, (int)Tp, total);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+extern "C" int pm_avgpool_time2(const void* x, void* out, int64_t B, int64_t T, int64_t d, void* stream) {
+  if (!x || !out || B < 0 || T < 2 || d <= 0) return PM_EINVAL;
+  if (d % 8) return PM_EUNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)out) & 15) return PM_EALIGN;
+  if (B == 0) return PM_OK;
+  const int64_t To = T / 2, total = B * To * (d / 8);
+  if (T > 0x7fffffff || (total + 255) / 256 > 0x7fffffff) return PM_EINVAL;
+  hipLaunchKernelGGL(avgpool_time2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x, (bf16*)out, (int)T, (int)To, (int)(d / 8), total);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}

@@ -43,6 +43,11 @@ SIGNATURES = {
     "pm_dec_sample_topk": ([_p, _l, _l, _l, ctypes.c_uint64, _p, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p], c_int),
     "pm_dec_next_token": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _l, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
+    "pm_layernorm_ex": ([_p, _l, _i, _p, _p, _f, _i, _p, _l, _i, _p, _l, _i, _l, _l, _p], c_int),
+    "pm_w2v_stem0_chunks": ([_l], c_int64),
+    "pm_w2v_stem0": ([_p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
+    "pm_group_windows": ([_p, _l, _i, _p, _l, _l, _l, _l, _l, _l, _l, _p], c_int),
+    "pm_avgpool_time2": ([_p, _p, _l, _l, _l, _p], c_int),
     "pm_attention_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
     "pm_attention_bias_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p, _l, _l, _l, _p], c_int),
     "pm_attention_generic_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _l, _i, _p, _l, _l, _l, _p], c_int),

@@ -107,17 +107,30 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none
     return out
 
 
-def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype | None = None) -> Tensor:
-    """Row-wise LayerNorm of x (M, d) (bf16 | f32) with f32 gamma / beta."""
-    _cuda(x, gamma, beta)
+def layernorm(x: Tensor, gamma: Tensor | None, beta: Tensor | None, eps: float, out_dtype: torch.dtype | None = None,
+              act: str = "none", resid: Tensor | None = None) -> Tensor:
+    """Row-wise LayerNorm of x (M, d) (bf16 | f32) with f32 gamma / beta (both None = no affine), optionally followed by
+    GELU and a residual add (pm_layernorm_ex)."""
+    _cuda(x, gamma, beta, resid)
     _need(x.dim() == 2 and x.stride(1) == 1, "layernorm: x must be (M, d), row-major")
     M, d = x.shape
-    _need(gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == d and beta.numel() == d,
-          "layernorm: gamma / beta must be f32 (d)")
+    _need((gamma is None) == (beta is None), "layernorm: gamma and beta come together")
+    if gamma is not None:
+        _need(gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == d and beta.numel() == d,
+              "layernorm: gamma / beta must be f32 (d)")
+    if resid is not None:
+        _need(resid.shape == x.shape and resid.stride(1) == 1, "layernorm: resid must be (M, d), row-major")
     out = torch.empty((M, d), dtype=out_dtype or x.dtype, device=x.device)
-    rc = _launch("layernorm", float(M * d * (x.element_size() + out.element_size())), lambda: lib().pm_layernorm(
-        x.data_ptr(), x.stride(0), _dt(x), gamma.data_ptr(), beta.data_ptr(), float(eps),
-        out.data_ptr(), out.stride(0), _dt(out), M, d, _stream()))
+    gp, bp = (gamma.data_ptr(), beta.data_ptr()) if gamma is not None else (None, None)
+    nbytes = float(M * d * (x.element_size() + out.element_size() + (resid.element_size() if resid is not None else 0)))
+    if act == "none" and resid is None and gamma is not None:
+        rc = _launch("layernorm", nbytes, lambda: lib().pm_layernorm(
+            x.data_ptr(), x.stride(0), _dt(x), gp, bp, float(eps), out.data_ptr(), out.stride(0), _dt(out), M, d, _stream()))
+    else:
+        rc = _launch("layernorm", nbytes, lambda: lib().pm_layernorm_ex(
+            x.data_ptr(), x.stride(0), _dt(x), gp, bp, float(eps), ACT[act],
+            resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
+            _dt(resid) if resid is not None else 0, out.data_ptr(), out.stride(0), _dt(out), M, d, _stream()))
     check(rc, f"pm_layernorm(M={M}, d={d})")
     return out
 
@@ -188,7 +201,7 @@ def vit_tokens(imgs: Tensor, w2d: Tensor, bias: Tensor, pe: Tensor, cls: Tensor 
 
 def linear_strided(x: Tensor, *, M: int, K: int, row_stride: int, rows_per_batch: int, batch_stride: int, w: Tensor,
                    bias: Tensor | None = None, act: str = "none", resid: Tensor | None = None, resid_period: int = 0,
-                   out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+                   out_dtype: torch.dtype = torch.bfloat16, out: Tensor | None = None) -> Tensor:
     """pm_linear_bf16_ex: row m of the A operand is the K contiguous bf16 values at
     x.flat[(m // rows_per_batch) * batch_stride + (m % rows_per_batch) * row_stride : ... + K] (rows may overlap:
     that is how a strided conv window is expressed); resid rows repeat every resid_period rows."""
@@ -205,13 +218,68 @@ def linear_strided(x: Tensor, *, M: int, K: int, row_stride: int, rows_per_batch
     if resid is not None:
         _need(resid.dim() == 2 and resid.shape[1] == N and resid.stride(1) == 1, "linear_strided: resid (rows, N)")
         _need(resid.shape[0] >= (resid_period or M), "linear_strided: resid has too few rows")
-    out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    else:  # e.g. a column slice of a wider matrix (one group of a grouped conv)
+        _need(out.is_cuda and out.shape == (M, N) and out.stride(1) == 1, "linear_strided: out must be (M, N) with unit column stride")
     rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16_ex(
         x.data_ptr(), row_stride, rows_per_batch, batch_stride, w.data_ptr(), w.stride(0),
         bias.data_ptr() if bias is not None else None, resid.data_ptr() if resid is not None else None,
         resid.stride(0) if resid is not None else 0, _dt(resid) if resid is not None else 0, resid_period,
         out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream()))
     check(rc, f"pm_linear_bf16_ex(M={M}, N={N}, K={K})")
+    return out
+
+
+def w2v_stem0(x: Tensor, w: Tensor, bias: Tensor | None, norm: str, gamma: Tensor | None, beta: Tensor | None,
+              eps: float, stride: int) -> Tensor:
+    """pm_w2v_stem0: f32 waveform (B, L) -> bf16 (B, T0, C0) = GELU(norm(Conv1d(1, C0, k, stride)(x))), time-major.
+    norm: "none" | "layer" (over channels) | "instance" (over time, per clip and channel)."""
+    _cuda(x, w, bias, gamma, beta)
+    _need(x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous(), "w2v_stem0: x must be contiguous f32 (B, L)")
+    _need(w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous(), "w2v_stem0: w must be contiguous f32 (C0, k)")
+    for t in (bias, gamma, beta):
+        _need(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == w.shape[0]), "w2v_stem0: f32 (C0) vectors")
+    B, L = x.shape
+    C0, k = w.shape
+    _need(L >= k, f"w2v_stem0: waveform shorter than the kernel ({L} < {k})")
+    T0 = (L - k) // stride + 1
+    mode = {"none": 0, "layer": 1, "instance": 2}[norm]
+    out = torch.empty((B, T0, C0), dtype=torch.bfloat16, device=x.device)
+    partials = stats = None
+    if mode == 2:
+        partials = torch.empty((B, int(lib().pm_w2v_stem0_chunks(T0)), C0, 2), dtype=torch.float32, device=x.device)
+        stats = torch.empty((B, C0, 2), dtype=torch.float32, device=x.device)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    rc = _launch("w2v_stem0", float(B * T0 * C0 * 2 + B * L * 4 * (2 if mode == 2 else 1)), lambda: lib().pm_w2v_stem0(
+        x.data_ptr(), w.data_ptr(), ptr(bias), mode, ptr(gamma), ptr(beta), float(eps), ptr(partials), ptr(stats),
+        out.data_ptr(), B, L, C0, k, stride, _stream()))
+    check(rc, f"pm_w2v_stem0(B={B}, L={L}, C0={C0}, k={k}, norm={norm})")
+    return out
+
+
+def group_windows(x: Tensor, groups: int, cgp: int, pad_left: int, pad_right: int) -> Tensor:
+    """pm_group_windows: (B, T, d) bf16 | f32 -> bf16 (B, G, pad_left + T + pad_right, cgp), group-major, zero-padded."""
+    _cuda(x)
+    _need(x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1), "group_windows: (B, T, d) rows")
+    B, T, d = x.shape
+    _need(d % groups == 0, "group_windows: d must divide into the groups")
+    cg = d // groups
+    out = torch.empty((B, groups, pad_left + T + pad_right, cgp), dtype=torch.bfloat16, device=x.device)
+    rc = _launch("group_windows", float(x.numel() * x.element_size() + out.numel() * 2), lambda: lib().pm_group_windows(
+        x.data_ptr(), x.stride(1), _dt(x), out.data_ptr(), B, T, groups, cg, cgp, pad_left, pad_right, _stream()))
+    check(rc, f"pm_group_windows(B={B}, T={T}, d={d}, G={groups})")
+    return out
+
+
+def avgpool_time2(x: Tensor) -> Tensor:
+    """pm_avgpool_time2: bf16 (B, T, d) -> (B, T // 2, d), mean of adjacent steps."""
+    _cuda(x)
+    _need(x.dim() == 3 and x.dtype == torch.bfloat16 and x.is_contiguous(), "avgpool_time2: contiguous bf16 (B, T, d)")
+    B, T, d = x.shape
+    out = torch.empty((B, T // 2, d), dtype=torch.bfloat16, device=x.device)
+    rc = _launch("avgpool_time2", float(3 * out.numel() * 2), lambda: lib().pm_avgpool_time2(x.data_ptr(), out.data_ptr(), B, T, d, _stream()))
+    check(rc, f"pm_avgpool_time2(B={B}, T={T}, d={d})")
     return out
 
 

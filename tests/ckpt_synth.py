@@ -206,6 +206,56 @@ def openai_gpt_params(n_layers, d, vocab, max_pos, seed=0):
     return ps
 
 
+def hf_wav2vec2(kind, n_layers, d, dims, kernels, *, legacy: bool, stem_bias: bool, pe_kernel: int, seed=0):
+    """Wav2Vec2Model / HubertModel ("wav2vec2"), Data2VecAudioModel ("data2vec") or SEWModel ("sew") layout: conv stem,
+    feature projection, weight-normed (g, v) positional conv (five plain convs for data2vec), post-LN-named encoder."""
+    sd = {}
+
+    def put(k, shape):
+        sd[k] = _t(k, shape, seed)
+
+    c_in = 1
+    for i, (c, k) in enumerate(zip(dims, kernels)):
+        b = f"feature_extractor.conv_layers.{i}."
+        put(b + "conv.weight", (c, c_in, k))
+        if stem_bias:
+            put(b + "conv.bias", (c,))
+        if not legacy or i == 0:
+            put(b + "layer_norm.weight", (c,))
+            put(b + "layer_norm.bias", (c,))
+        c_in = c
+    ln, lin = ("layer_norm", "feature_projection") if kind == "sew" else ("feature_projection.layer_norm", "feature_projection.projection")
+    put(ln + ".weight", (c_in,))
+    put(ln + ".bias", (c_in,))
+    if c_in != d:
+        put(lin + ".weight", (d, c_in))
+        put(lin + ".bias", (d,))
+    if kind == "data2vec":
+        for i in range(5):
+            put(f"encoder.pos_conv_embed.layers.{i}.conv.weight", (d, d // 16, pe_kernel))
+            put(f"encoder.pos_conv_embed.layers.{i}.conv.bias", (d,))
+    else:
+        sd["encoder.pos_conv_embed.conv.weight_g"] = _t("pe.weight_g", (1, 1, pe_kernel), seed).abs() + 0.5
+        put("encoder.pos_conv_embed.conv.weight_v", (d, d // 16, pe_kernel))
+        put("encoder.pos_conv_embed.conv.bias", (d,))
+    put("encoder.layer_norm.weight", (d,))
+    put("encoder.layer_norm.bias", (d,))
+    for i in range(n_layers):
+        b = f"encoder.layers.{i}."
+        for name, shape in (("attention.q_proj", (d, d)), ("attention.k_proj", (d, d)), ("attention.v_proj", (d, d)),
+                            ("attention.out_proj", (d, d)), ("feed_forward.intermediate_dense", (4 * d, d)),
+                            ("feed_forward.output_dense", (d, 4 * d))):
+            put(b + name + ".weight", shape)
+            put(b + name + ".bias", (shape[0],))
+        for nm in ("layer_norm", "final_layer_norm"):
+            put(b + nm + ".weight", (d,))
+            put(b + nm + ".bias", (d,))
+    if kind == "sew":
+        put("encoder.upsample.projection.weight", (2 * d, d))
+        put("encoder.upsample.projection.bias", (2 * d,))
+    return sd
+
+
 def state_digest(sd) -> dict:
     """name -> [sum, sum |x|, position-weighted sum] (fp64) of every tensor of a loaded model."""
     out = {}

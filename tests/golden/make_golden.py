@@ -352,9 +352,63 @@ def g_text():
     print("text_converters.json", os.path.getsize(os.path.join(HERE, "text_converters.json")) // 1024, "KiB")
 
 
+def g_audio_enc():
+    """the wav2vec2 family on synthweights at the sizes of the reference's own tests
+    (tests/audio/test_wav2vec2.py:12,17: x (2, 6400), Wav2Vec2(2, 64)) plus d = 128 variants covering the legacy
+    (instance-norm, bias-free) stem, post-norm, data2vec's five-layer positional conv and SEW's down / up-sampling
+    (odd frame count), and digests of what the reference's HF loaders make of synthetic upstream checkpoints."""
+    import io
+    from contextlib import redirect_stdout
+
+    from pytorch_models.audio import SEW, Data2VecAudio, Wav2Vec2
+
+    sys.path.insert(2, os.path.join(ROOT, "tests"))
+    import ckpt_synth as C
+
+    out, rec = {}, {}
+    x = synth_input("w2v_x", (2, 6400), 81)
+    cases = dict(
+        w2v_d64=(lambda: Wav2Vec2(2, 64), 82),
+        w2v_legacy_post_d128=(lambda: Wav2Vec2(2, 128, stem_bias=False, stem_legacy=True, pre_norm=False), 83),
+        d2v_d128=(lambda: Data2VecAudio(2, 128), 84),
+        sew_d128=(lambda: SEW(2, 128), 85),
+    )
+    for name, (make, seed) in cases.items():
+        m = make().eval()
+        fill_module(m, seed)
+        feat = m.feature_encoder(x.unsqueeze(1)).transpose(1, 2)  # (B, T, C)
+        out[name + "_feat_s8"] = feat[..., ::8]
+        out[name + "_proj"] = m.proj(feat)
+        out[name] = m(x)
+    # 6400 samples give 19 frames: odd, so SEW appends a zero frame after up-sampling (sew.py:37-38); 6080 give 18
+    assert out["sew_d128"].shape[1] % 2 == 1
+    m = SEW(2, 128).eval()
+    fill_module(m, 85)
+    out["sew_d128_even"] = m(x[:, :6080])
+    assert out["sew_d128_even"].shape[1] % 2 == 0
+    loaders = dict(
+        hf_wav2vec2=(lambda: Wav2Vec2(2, 128), dict(kind="wav2vec2", legacy=False, stem_bias=True, pe_kernel=128)),
+        hf_wav2vec2_base=(lambda: Wav2Vec2(2, 128, stem_bias=False, stem_legacy=True, pre_norm=False),
+                          dict(kind="wav2vec2", legacy=True, stem_bias=False, pe_kernel=128)),
+        hf_data2vec=(lambda: Data2VecAudio(2, 128), dict(kind="data2vec", legacy=False, stem_bias=False, pe_kernel=19)),
+        hf_sew=(lambda: SEW(2, 128), dict(kind="sew", legacy=True, stem_bias=True, pe_kernel=31)),
+    )
+    for name, (make, kw) in loaders.items():
+        m = make()
+        kind = kw.pop("kind")
+        with redirect_stdout(io.StringIO()) as so:
+            m.load_hf_state_dict(C.hf_wav2vec2(kind, 2, 128, m.STEM_DIMS, m.STEM_KERNELS, seed=86, **kw))
+        assert "dict_keys([])" in so.getvalue(), so.getvalue()
+        rec[name] = C.state_digest(m.state_dict())
+    save("audio_enc", dict(x_seed=81), **out)
+    with open(os.path.join(HERE, "audio_converters.json"), "w") as f:
+        json.dump(rec, f, indent=0, sort_keys=True)
+    print("audio_converters.json", os.path.getsize(os.path.join(HERE, "audio_converters.json")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters", "text"]
+    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters", "text", "audio_enc"]
     table = dict(blocks=g_blocks, mha=g_mha, sdpa=g_sdpa_alignment, vit=g_vit, audio=g_audio, whisper=g_whisper,
-                 geometry=g_geometry, converters=g_converters, text=g_text)
+                 geometry=g_geometry, converters=g_converters, text=g_text, audio_enc=g_audio_enc)
     for w in which:
         table[w]()
