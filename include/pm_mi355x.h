@@ -105,6 +105,19 @@ int pm_w2v_stem0(const float* x, const float* w, const float* bias, int norm, co
 int pm_group_windows(const void* x, int64_t ldx, int x_dtype, void* out, int64_t B, int64_t T, int64_t G, int64_t cg,
                      int64_t cgp, int64_t pad_left, int64_t pad_right, void* stream);
 
+/* Grouped Conv1d over time with few channels per group, fused bias / activation / residual (the positional conv of
+ * audio/wav2vec2.py:70-74, audio/data2vec_audio.py:25, audio/sew.py:24), on the buffer pm_group_windows builds:
+ *   y[b*To + t, g*cg + n] = act(bias[g*cg + n] + sum_{tap < k, c < cg} xg[b, g, t*stride + tap, c] * w[g, n, tap*cgp + c])
+ *                           + resid[b*To + t, g*cg + n],          To = (Tp - k) / stride + 1.
+ * xg: bf16 (B, G, Tp, cgp); w: bf16 (G, cg, Kp), K order (tap, channel), zero-padded from k*cgp to Kp (% 64 == 0,
+ * < 64 of padding); bias: f32 (G*cg) or NULL; resid: bf16 rows of stride ldr, or NULL; y: bf16 rows of stride ldy;
+ * act: PM_ACT_NONE | PM_ACT_GELU.  The distinct input rows of a tile stay resident in LDS (see csrc/grouped_conv.hip).
+ * pm_grouped_conv_supported(cg, cgp) == 1 for cg % 4 == 0 and cgp in {8, 16, 32, 48, 64} with cgp - cg < 8. */
+int pm_grouped_conv_supported(int64_t cg, int64_t cgp);
+int pm_grouped_conv_bf16(const void* xg, const void* w, const float* bias, const void* resid, int64_t ldr, void* y,
+                         int64_t ldy, int64_t B, int64_t G, int64_t Tp, int64_t cg, int64_t cgp, int64_t k, int64_t stride,
+                         int64_t Kp, int act, void* stream);
+
 /* F.avg_pool1d(x, 2) over time on (B, T, d) bf16 -> (B, T / 2, d) bf16 (audio/sew.py:33; a trailing odd row is dropped). */
 int pm_avgpool_time2(const void* x, void* out, int64_t B, int64_t T, int64_t d, void* stream);
 

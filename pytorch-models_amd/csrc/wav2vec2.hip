@@ -31,72 +31,101 @@ __global__ __launch_bounds__(256) void w2v_stem0_kernel(const float* __restrict_
                                                         const float* __restrict__ beta, const float* __restrict__ stats,
                                                         float* __restrict__ partials, float eps, bf16* __restrict__ out,
                                                         int64_t L, int T0, int C0, int stride, int nchunk) {
+  // The kernel is VALU-bound before it is HBM-bound (80 FMAs + 8 GELUs per lane and step against a 16-byte store), so
+  // all per-channel arithmetic is on channel PAIRS: v_pk_fma_f32 for the taps, the packed polynomial GELU of common.h.
   __shared__ float red[4][512][2];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int c0 = lane * 8;
   const bool on = c0 < C0;  // C0 % 8 == 0: a lane's 8 channels are all inside or all outside
-  float wr[KT][8], bs[8], g[8], bt[8], mu[8], rs[8];
+  f32x2 wr[KT][4], bs[4], g[4], bt[4], mu[4], rs[4];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = on ? c0 + i : 0;
 #pragma unroll
-    for (int j = 0; j < KT; ++j) wr[j][i] = on ? w[c * KT + j] : 0.f;
-    bs[i] = (on && bias) ? bias[c] : 0.f;
-    g[i] = (on && gamma) ? gamma[c] : 1.f;
-    bt[i] = (on && beta) ? beta[c] : 0.f;
+    for (int j = 0; j < KT; ++j) wr[j][i >> 1][i & 1] = on ? w[c * KT + j] : 0.f;
+    bs[i >> 1][i & 1] = (on && bias) ? bias[c] : 0.f;
+    g[i >> 1][i & 1] = (on && gamma) ? gamma[c] : 1.f;
+    bt[i >> 1][i & 1] = (on && beta) ? beta[c] : 0.f;
     if constexpr (MODE == MODE_INSTANCE) {
-      mu[i] = stats[((int64_t)b * C0 + c) * 2];
-      rs[i] = stats[((int64_t)b * C0 + c) * 2 + 1];
+      mu[i >> 1][i & 1] = stats[((int64_t)b * C0 + c) * 2];
+      rs[i >> 1][i & 1] = stats[((int64_t)b * C0 + c) * 2 + 1];
     }
   }
-  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE == MODE_INSTANCE) {  // (v - mu) * rs * g + bt = v * (rs g) + (bt - mu rs g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      g[i] = rs[i] * g[i];
+      bt[i] = bt[i] - mu[i] * g[i];
+    }
+  }
+  const f32x2 zero2 = {0.f, 0.f};
+  f32x2 s8[4] = {zero2, zero2, zero2, zero2}, q8[4] = {zero2, zero2, zero2, zero2};
   const float* xb = x + (int64_t)b * L;
   const int t_end = min((chunk + 1) * TCH, T0);
   const float inv_c = 1.0f / (float)C0;
-  for (int t = chunk * TCH + wave; t < t_end; t += 4) {
-    const float* xs = xb + (int64_t)t * stride;  // wave-uniform: the taps arrive by scalar loads
-    float v[8];
+  // wave-uniform addresses: the taps arrive by scalar loads, requested one step ahead of their use
+  float xn[KT];
+  {
+    const float* xs = xb + (int64_t)min(chunk * TCH + wave, T0 - 1) * stride;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = bs[i];
+    for (int j = 0; j < KT; ++j) xn[j] = xs[j];
+  }
+  for (int t = chunk * TCH + wave; t < t_end; t += 4) {
+    float xc[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) xc[j] = xn[j];
+    {
+      const float* xs = xb + (int64_t)min(t + 4, T0 - 1) * stride;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) xn[j] = xs[j];
+    }
+    f32x2 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = bs[i];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-      const float xv = xs[j];
+      const float xv = xc[j];
+      const f32x2 xv2 = {xv, xv};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fmaf(wr[j][i], xv, v[i]);
+      for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_fma(wr[j][i], xv2, v[i]);
     }
     if constexpr (MODE == MODE_STATS) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 4; ++i) {
         s8[i] += v[i];
-        q8[i] = fmaf(v[i], v[i], q8[i]);
+        q8[i] = __builtin_elementwise_fma(v[i], v[i], q8[i]);
       }
       continue;
     }
     if constexpr (MODE == MODE_LAYERNORM) {  // over the C0 channels of this step (LayerNorm1d, wav2vec2.py:14-16)
-      float s = 0.f;
+      const f32x2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
+      const float mean = wave_sum(on ? s2[0] + s2[1] : 0.f) * inv_c;
+      const f32x2 mean2 = {mean, mean};
+      f32x2 q2 = zero2;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += on ? v[i] : 0.f;
-      const float mean = wave_sum(s) * inv_c;
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[i] -= mean;
-        q = on ? fmaf(v[i], v[i], q) : q;
+      for (int i = 0; i < 4; ++i) {
+        v[i] -= mean2;
+        q2 = __builtin_elementwise_fma(v[i], v[i], q2);
       }
-      const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+      const float rstd = rsqrtf(wave_sum(on ? q2[0] + q2[1] : 0.f) * inv_c + eps);
+      const f32x2 rstd2 = {rstd, rstd};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i] * rstd, g[i], bt[i]);
+      for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_fma(v[i] * rstd2, g[i], bt[i]);
     }
     if constexpr (MODE == MODE_INSTANCE) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = fmaf((v[i] - mu[i]) * rs[i], g[i], bt[i]);
+      for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_fma(v[i], g[i], bt[i]);
     }
     if (on) {
       bf16x8 o;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o[i] = (bf16)apply_act<PM_ACT_GELU, true>(v[i]);
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 a = gelu_poly2(v[i]);
+        o[2 * i] = (bf16)a[0];
+        o[2 * i + 1] = (bf16)a[1];
+      }
       *(bf16x8*)(out + ((int64_t)b * T0 + t) * C0 + c0) = o;
     }
   }
@@ -104,8 +133,8 @@ __global__ __launch_bounds__(256) void w2v_stem0_kernel(const float* __restrict_
     if (on) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        red[wave][c0 + i][0] = s8[i];
-        red[wave][c0 + i][1] = q8[i];
+        red[wave][c0 + i][0] = s8[i >> 1][i & 1];
+        red[wave][c0 + i][1] = q8[i >> 1][i & 1];
       }
     }
     __syncthreads();

@@ -47,6 +47,8 @@ SIGNATURES = {
     "pm_w2v_stem0_chunks": ([_l], c_int64),
     "pm_w2v_stem0": ([_p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_group_windows": ([_p, _l, _i, _p, _l, _l, _l, _l, _l, _l, _l, _p], c_int),
+    "pm_grouped_conv_supported": ([_l, _l], c_int),
+    "pm_grouped_conv_bf16": ([_p, _p, _p, _p, _l, _p, _l, _l, _l, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
     "pm_avgpool_time2": ([_p, _p, _l, _l, _l, _p], c_int),
     "pm_attention_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
     "pm_attention_bias_bf16": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _i, _p, _l, _l, _l, _p], c_int),

@@ -272,6 +272,34 @@ def group_windows(x: Tensor, groups: int, cgp: int, pad_left: int, pad_right: in
     return out
 
 
+def grouped_conv_supported(cg: int, cgp: int) -> bool:
+    return bool(lib().pm_grouped_conv_supported(cg, cgp))
+
+
+def grouped_conv(xg: Tensor, w: Tensor, bias: Tensor | None, k: int, stride: int, cg: int, act: str = "none",
+                 resid: Tensor | None = None) -> Tensor:
+    """pm_grouped_conv_bf16: xg bf16 (B, G, Tp, cgp) from group_windows, w bf16 (G, cg, Kp) (K order (tap, channel), zero-padded to
+    a multiple of 64) -> bf16 (B * To, G * cg) = act(conv + bias) + resid."""
+    _cuda(xg, w, bias, resid)
+    _need(xg.dim() == 4 and xg.dtype == torch.bfloat16 and xg.is_contiguous(), "grouped_conv: xg must be contiguous bf16 (B, G, Tp, cgp)")
+    B, G, Tp, cgp = xg.shape
+    _need(w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[:2] == (G, cg), "grouped_conv: w must be contiguous bf16 (G, cg, Kp)")
+    Kp = w.shape[2]
+    To = (Tp - k) // stride + 1
+    d = G * cg
+    if bias is not None:
+        _need(bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == d, "grouped_conv: bias f32 (G*cg)")
+    if resid is not None:
+        _need(resid.dtype == torch.bfloat16 and resid.shape == (B * To, d) and resid.stride(1) == 1, "grouped_conv: resid bf16 (B*To, d)")
+    out = torch.empty((B * To, d), dtype=torch.bfloat16, device=xg.device)
+    rc = _launch("grouped_conv", 2.0 * B * To * d * k * cg, lambda: lib().pm_grouped_conv_bf16(
+        xg.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+        resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0, out.data_ptr(), out.stride(0),
+        B, G, Tp, cg, cgp, k, stride, Kp, ACT[act], _stream()))
+    check(rc, f"pm_grouped_conv_bf16(B={B}, G={G}, Tp={Tp}, cg={cg}, k={k}, stride={stride})")
+    return out
+
+
 def avgpool_time2(x: Tensor) -> Tensor:
     """pm_avgpool_time2: bf16 (B, T, d) -> (B, T // 2, d), mean of adjacent steps."""
     _cuda(x)

@@ -1,6 +1,6 @@
 """data2vec (audio) on MI355X, drop-in for /root/reference pytorch_models/audio/data2vec_audio.py: the Wav2Vec2
 layer-norm stem and post-norm encoder with a five-layer positional conv (grouped Conv1d(k 19) -> LayerNorm1d without
-affine -> GELU; data2vec_audio.py:23-30).  Each layer = pm_group_windows + 16 strided-window GEMMs (bias in the
+affine -> GELU; data2vec_audio.py:23-30).  Each layer = pm_group_windows + pm_grouped_conv_bf16 (bias in the
 epilogue) + one pm_layernorm_ex (no affine, GELU; the last one also adds the "+ x" residual)."""
 from __future__ import annotations
 

@@ -10,8 +10,8 @@ never happen and each piece lands on a kernel that already exists for the transf
                                                      GELU in the epilogue (legacy stem: no norm after layer 0) or
                                                      followed by pm_layernorm_ex (channel LayerNorm + GELU)
     proj                    -> pm_layernorm + pm_linear_bf16
-    pe_conv (16 groups)     -> pm_group_windows + one pm_linear_bf16_ex per group (bias, GELU and the "+ x" residual
-                               in its epilogue, written into the group's column slice)
+    pe_conv (16 groups)     -> pm_group_windows + pm_grouped_conv_bf16 (a tile's distinct input rows resident in LDS, the
+                               group's weight streamed; bias, GELU and the "+ x" residual in its epilogue)
     layers, norm            -> transformer.Encoder / LayerNorm
 
 No CPU path, inference only (dropout is the identity).
@@ -123,16 +123,19 @@ class Wav2Vec2(nn.Module):
         self.norm = LayerNorm(d_model)
         self.pre_norm = pre_norm
 
-    # ---- grouped positional conv as G strided-window GEMMs
+    # ---- grouped positional conv: pm_group_windows + pm_grouped_conv_bf16 (input span resident in LDS)
     @staticmethod
     def _group_weights(conv: nn.Conv1d):
         def build():
             d, cg, k = conv.weight.shape
             G = conv.groups
             cgp = (cg + 7) // 8 * 8
-            w = torch.zeros(G, d // G, k, cgp, dtype=torch.bfloat16, device=conv.weight.device)
-            w[..., :cg] = conv.weight.detach().view(G, d // G, cg, k).permute(0, 1, 3, 2).to(torch.bfloat16)
-            return w.view(G, d // G, k * cgp), conv.bias.detach().float().contiguous(), cgp
+            Kp = (k * cgp + 63) // 64 * 64
+            w = torch.zeros(G, d // G, Kp, dtype=torch.bfloat16, device=conv.weight.device)  # K order (tap, channel), zero tail
+            wk = torch.zeros(G, d // G, k, cgp, dtype=torch.bfloat16, device=conv.weight.device)
+            wk[..., :cg] = conv.weight.detach().view(G, d // G, cg, k).permute(0, 1, 3, 2).to(torch.bfloat16)
+            w[..., : k * cgp] = wk.view(G, d // G, k * cgp)
+            return w, conv.bias.detach().float().contiguous(), cgp
 
         return derived(conv, "groups", (conv.weight, conv.bias), build)
 
@@ -141,17 +144,22 @@ class Wav2Vec2(nn.Module):
         """act(Conv1d(groups=G)(pad(h))) [+ resid] on time-major bf16 h (B, T, d) -> (B, T_out, d_out)."""
         w, b, cgp = Wav2Vec2._group_weights(conv)
         B, T, _ = h.shape
-        G, co, K = w.shape
+        G, co, Kp = w.shape
         k, s = conv.kernel_size[0], conv.stride[0]
         Tp = T + pad[0] + pad[1]
         To = (Tp - k) // s + 1
-        xg = ops.group_windows(h, G, cgp, pad[0], pad[1]).view(-1)  # (B, G, Tp, cgp)
-        out = torch.empty((B * To, G * co), dtype=torch.bfloat16, device=h.device)
+        cg = conv.in_channels // G
+        xg = ops.group_windows(h, G, cgp, pad[0], pad[1])  # (B, G, Tp, cgp)
         r2 = None if resid is None else resid.reshape(B * To, G * co)
+        if co == cg and ops.grouped_conv_supported(cg, cgp):
+            return ops.grouped_conv(xg, w, b, k, s, cg, act, r2).view(B, To, G * co)
+        # channel counts the resident-span kernel does not cover: one strided-window GEMM per group
+        out = torch.empty((B * To, G * co), dtype=torch.bfloat16, device=h.device)
+        xf = xg.view(-1)
         for g in range(G):
             cols = slice(g * co, (g + 1) * co)
-            ops.linear_strided(xg[g * Tp * cgp:], M=B * To, K=K, row_stride=s * cgp, rows_per_batch=To, batch_stride=G * Tp * cgp,
-                               w=w[g], bias=b[cols], act=act, resid=None if r2 is None else r2[:, cols], out=out[:, cols])
+            ops.linear_strided(xf[g * Tp * cgp:], M=B * To, K=k * cgp, row_stride=s * cgp, rows_per_batch=To, batch_stride=G * Tp * cgp,
+                               w=w[g][:, : k * cgp], bias=b[cols], act=act, resid=None if r2 is None else r2[:, cols], out=out[:, cols])
         return out.view(B, To, G * co)
 
     def _features(self, x: Tensor) -> Tensor:

@@ -127,15 +127,17 @@ def test_conv_layer_as_strided_window_gemm(C, Co, k, s, T):
 
 
 @pytest.mark.parametrize("d,k,pad,stride", [(768, 128, (64, 63), 1), (64, 128, (64, 63), 1), (128, 19, (9, 9), 1), (128, 31, (15, 14), 2),
-                                            (1024, 128, (64, 63), 1)])
+                                            (1024, 128, (64, 63), 1), (512, 31, (15, 14), 2), (256, 19, (9, 9), 1),
+                                            (160, 19, (9, 9), 1)])
 def test_grouped_positional_conv(d, k, pad, stride):
-    """wav2vec2.py:70-74 / data2vec_audio.py:25 / sew.py:24 as 16 strided-window GEMMs over the regrouped buffer."""
+    """wav2vec2.py:70-74 / data2vec_audio.py:25 / sew.py:24 on pm_grouped_conv_bf16 (48 / 4 / 8 / 64 / 32 / 16 channels per
+    group; 10 channels per group falls back to one strided-window GEMM per group)."""
     from pytorch_models.audio import Wav2Vec2
 
     conv = torch.nn.Conv1d(d, d, k, stride=stride, groups=16)
     fill_module(conv, 10)
     bf16_round_(conv)
-    B, T = 2, 51
+    B, T = (2, 51) if d != 768 else (3, 499)  # 499 steps: two 256-step tiles per clip, the second one ragged
     h = synth_input("pe_x", (B, T, d), 10).to(torch.bfloat16)
     To = (T + pad[0] + pad[1] - k) // stride + 1
     r = synth_input("pe_r", (B, To, d), 10).to(torch.bfloat16)
