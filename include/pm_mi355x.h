@@ -89,11 +89,11 @@ int pm_layernorm_ex(const void* x, int64_t ldx, int x_dtype, const float* gamma,
  * Layer 0 (audio/wav2vec2.py:32-38 with in_dim 1): out[b, t, c] = GELU(norm(bias[c] + sum_j w[c, j] x[b, t*stride + j])),
  * T0 = (L - k) / stride + 1.  x: f32 (B, L); w: f32 (C0, k) = the Conv1d weight as stored; bias: f32 (C0) or NULL;
  * out: bf16 (B, T0, C0).  norm: PM_W2V_NORM_NONE | PM_W2V_NORM_LAYER (LayerNorm1d over channels, gamma / beta f32 (C0)) |
- * PM_W2V_NORM_INSTANCE (InstanceNorm1d(affine) over time per clip and channel: two passes over the waveform, scratch
- * partials f32 (B, pm_w2v_stem0_chunks(T0), C0, 2) and stats f32 (B, C0, 2) supplied by the caller; fixed reduction
- * order).  k == 10, C0 % 8 == 0, C0 <= 512. */
+ * PM_W2V_NORM_INSTANCE (InstanceNorm1d(affine) over time per clip and channel: the statistics come from the waveform's
+ * 10 x 10 lag products, see csrc/wav2vec2.hip; the caller supplies scratch partials f32 (pm_w2v_stem0_scratch_floats(B, T0))
+ * and stats f32 (B, C0, 2); fixed reduction order).  k == 10, C0 % 8 == 0, C0 <= 512. */
 enum { PM_W2V_NORM_NONE = 0, PM_W2V_NORM_LAYER = 1, PM_W2V_NORM_INSTANCE = 2 };
-int64_t pm_w2v_stem0_chunks(int64_t T0);
+int64_t pm_w2v_stem0_scratch_floats(int64_t B, int64_t T0);
 int pm_w2v_stem0(const float* x, const float* w, const float* bias, int norm, const float* gamma, const float* beta, float eps,
                  float* partials, float* stats, void* out, int64_t B, int64_t L, int64_t C0, int64_t k, int64_t stride,
                  void* stream);

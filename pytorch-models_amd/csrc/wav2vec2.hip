@@ -13,27 +13,31 @@
 // 1 KiB output row per step; HBM-bound on the output (2*C0 bytes per step; 32.8 MB per 10 s clip at C0 = 512).
 //
 // InstanceNorm1d (legacy stem: statistics over TIME per clip and channel) needs a global reduction before the first
-// output can be written.  The conv is recomputed instead of stored: pass 1 accumulates (sum, sum of squares) per
-// channel over 256-step chunks (fixed order, no atomics: bit-reproducible), a finalize kernel folds the chunks in fp64
-// into (mean, rstd), pass 2 recomputes the conv and writes the normalised activations.  10 FMAs per value twice is
-// cheaper than a 4-byte round trip.
+// output can be written.  Neither a stored conv output nor a second conv pass is needed for it: the conv is linear in
+// the waveform, so per clip  sum_t v[c, t] = sum_j w[c, j] S[j]  and  sum_t v[c, t]^2 = sum_{j, j'} w[c, j] w[c, j'] R[j][j']
+// with S[j] = sum_t x[s t + j] and R[j][j'] = sum_t x[s t + j] x[s t + j'] - 10 + 55 numbers per clip, whatever C0 is.
+// One pass over the waveform (640 KB per 10 s clip) accumulates them per 1024-step chunk in a fixed order (no atomics:
+// bit-reproducible), a finalize kernel folds the chunks in fp64 and evaluates the two forms per channel, centred
+// (variance = w^T (R/T - s s^T) w), into (mean, rstd); the normalising pass then computes the conv once.  (The first
+// version recomputed the conv for the statistics: 189 us + 37 us at 32 x 10 s; this one takes ~15 us.)
 #include "common.h"
 
 namespace {
 
-constexpr int TCH = 256;  // time steps per workgroup = statistics chunk
+constexpr int TCH = 256;  // time steps per workgroup of the conv pass
 
-enum { MODE_NONE = 0, MODE_LAYERNORM = 1, MODE_INSTANCE = 2, MODE_STATS = 3 };
+enum { MODE_NONE = 0, MODE_LAYERNORM = 1, MODE_INSTANCE = 2 };
+constexpr int ACH = 1024;      // time steps per workgroup of the autocorrelation pass
+constexpr int APART = 80;      // floats per (clip, chunk) partial: KT sums + KT (KT + 1) / 2 products, padded
 
 template <int KT, int MODE>
 __global__ __launch_bounds__(256) void w2v_stem0_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ stats,
-                                                        float* __restrict__ partials, float eps, bf16* __restrict__ out,
-                                                        int64_t L, int T0, int C0, int stride, int nchunk) {
+                                                        float eps, bf16* __restrict__ out, int64_t L, int T0, int C0,
+                                                        int stride) {
   // The kernel is VALU-bound before it is HBM-bound (80 FMAs + 8 GELUs per lane and step against a 16-byte store), so
   // all per-channel arithmetic is on channel PAIRS: v_pk_fma_f32 for the taps, the packed polynomial GELU of common.h.
-  __shared__ float red[4][512][2];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -61,7 +65,6 @@ __global__ __launch_bounds__(256) void w2v_stem0_kernel(const float* __restrict_
     }
   }
   const f32x2 zero2 = {0.f, 0.f};
-  f32x2 s8[4] = {zero2, zero2, zero2, zero2}, q8[4] = {zero2, zero2, zero2, zero2};
   const float* xb = x + (int64_t)b * L;
   const int t_end = min((chunk + 1) * TCH, T0);
   const float inv_c = 1.0f / (float)C0;
@@ -90,14 +93,6 @@ __global__ __launch_bounds__(256) void w2v_stem0_kernel(const float* __restrict_
       const f32x2 xv2 = {xv, xv};
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = __builtin_elementwise_fma(wr[j][i], xv2, v[i]);
-    }
-    if constexpr (MODE == MODE_STATS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s8[i] += v[i];
-        q8[i] = __builtin_elementwise_fma(v[i], v[i], q8[i]);
-      }
-      continue;
     }
     if constexpr (MODE == MODE_LAYERNORM) {  // over the C0 channels of this step (LayerNorm1d, wav2vec2.py:14-16)
       const f32x2 s2 = (v[0] + v[1]) + (v[2] + v[3]);
@@ -129,40 +124,81 @@ __global__ __launch_bounds__(256) void w2v_stem0_kernel(const float* __restrict_
       *(bf16x8*)(out + ((int64_t)b * T0 + t) * C0 + c0) = o;
     }
   }
-  if constexpr (MODE == MODE_STATS) {
-    if (on) {
+}
+
+// (S, R) of one ACH-step chunk of one clip: thread-private sums over its steps, then a fixed-order wave / workgroup fold
+template <int KT>
+__global__ __launch_bounds__(256) void w2v_autocorr_kernel(const float* __restrict__ x, float* __restrict__ partials, int64_t L,
+                                                           int T0, int stride, int nchunk) {
+  constexpr int NP = KT + KT * (KT + 1) / 2;
+  __shared__ float red[4][NP];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const float* xb = x + (int64_t)b * L;
+  float acc[NP];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        red[wave][c0 + i][0] = s8[i >> 1][i & 1];
-        red[wave][c0 + i][1] = q8[i >> 1][i & 1];
+  for (int p = 0; p < NP; ++p) acc[p] = 0.f;
+  const int t_end = min((chunk + 1) * ACH, T0);
+  for (int t = chunk * ACH + threadIdx.x; t < t_end; t += 256) {
+    float xv[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) xv[j] = xb[(int64_t)t * stride + j];
+    int p = KT;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      acc[j] += xv[j];
+#pragma unroll
+      for (int j2 = j; j2 < KT; ++j2) {
+        acc[p] = fmaf(xv[j], xv[j2], acc[p]);
+        ++p;
       }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C0; c += 256) {
-      const float s = ((red[0][c][0] + red[1][c][0]) + red[2][c][0]) + red[3][c][0];
-      const float q = ((red[0][c][1] + red[1][c][1]) + red[2][c][1]) + red[3][c][1];
-      float* p = partials + (((int64_t)b * nchunk + chunk) * C0 + c) * 2;
-      p[0] = s;
-      p[1] = q;
-    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float v = wave_sum(acc[p]);
+    if (lane == 0) red[wave][p] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    const int p = threadIdx.x;
+    partials[((int64_t)b * nchunk + chunk) * APART + p] = ((red[0][p] + red[1][p]) + red[2][p]) + red[3][p];
   }
 }
 
-__global__ __launch_bounds__(256) void w2v_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats,
-                                                                 int64_t BC, int C0, int nchunk, int T0, float eps) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= BC) return;
-  const int64_t b = i / C0, c = i - b * C0;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    const float* p = partials + ((b * nchunk + k) * C0 + c) * 2;
-    s += (double)p[0];
-    q += (double)p[1];
+// one workgroup per clip: fold the chunks in fp64, then per channel mean = w.S / T0 (+ bias) and the centred variance
+template <int KT>
+__global__ __launch_bounds__(256) void w2v_stats_finalize_kernel(const float* __restrict__ partials, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ stats, int C0,
+                                                                 int nchunk, int T0, float eps) {
+  constexpr int NP = KT + KT * (KT + 1) / 2;
+  __shared__ double tot[NP];
+  const int b = blockIdx.x;
+  if (threadIdx.x < NP) {
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += (double)partials[((int64_t)b * nchunk + k) * APART + threadIdx.x];
+    tot[threadIdx.x] = s / T0;
   }
-  const double mean = s / T0;
-  const double var = fmax(q / T0 - mean * mean, 0.0);  // biased, like InstanceNorm1d
-  stats[i * 2] = (float)mean;
-  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  __syncthreads();
+  for (int c = threadIdx.x; c < C0; c += 256) {
+    double wv[KT], mean = 0.0, var = 0.0;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      wv[j] = (double)w[c * KT + j];
+      mean += wv[j] * tot[j];
+    }
+    int p = KT;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int j2 = j; j2 < KT; ++j2) {
+        const double cov = tot[p++] - tot[j] * tot[j2];  // E[x_j x_j'] - E[x_j] E[x_j']
+        var += (j2 == j ? 1.0 : 2.0) * wv[j] * wv[j2] * cov;
+      }
+    var = fmax(var, 0.0);  // biased, like InstanceNorm1d
+    stats[((int64_t)b * C0 + c) * 2] = (float)(mean + (bias ? (double)bias[c] : 0.0));
+    stats[((int64_t)b * C0 + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // out[b][g][pl + t][c] = x[b][t][g*cg + c] (bf16), zero for the pl leading / pr trailing rows and for c in [cg, cgp)
@@ -222,17 +258,16 @@ __global__ __launch_bounds__(256) void avgpool_time2_kernel(const bf16* __restri
 
 template <int MODE>
 int launch_stem0(int k, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias, const float* gamma,
-                 const float* beta, const float* stats, float* partials, float eps, bf16* out, int64_t L, int T0, int C0,
-                 int stride, int nchunk) {
+                 const float* beta, const float* stats, float eps, bf16* out, int64_t L, int T0, int C0, int stride) {
   if (k != 10) return PM_EUNSUPPORTED;  // every model of the family opens with Conv1d(1, C0, 10, 5)
-  hipLaunchKernelGGL((w2v_stem0_kernel<10, MODE>), grid, dim3(256), 0, st, x, w, bias, gamma, beta, stats, partials, eps, out, L,
-                     T0, C0, stride, nchunk);
+  hipLaunchKernelGGL((w2v_stem0_kernel<10, MODE>), grid, dim3(256), 0, st, x, w, bias, gamma, beta, stats, eps, out, L, T0, C0,
+                     stride);
   return PM_OK;
 }
 
 }  // namespace
 
-extern "C" int64_t pm_w2v_stem0_chunks(int64_t T0) { return (T0 + TCH - 1) / TCH; }
+extern "C" int64_t pm_w2v_stem0_scratch_floats(int64_t B, int64_t T0) { return B * ((T0 + ACH - 1) / ACH) * APART; }
 
 extern "C" int pm_w2v_stem0(const float* x, const float* w, const float* bias, int norm, const float* gamma, const float* beta,
                             float eps, float* partials, float* stats, void* out, int64_t B, int64_t L, int64_t C0, int64_t k,
@@ -243,7 +278,7 @@ extern "C" int pm_w2v_stem0(const float* x, const float* w, const float* bias, i
   if (norm == PM_W2V_NORM_INSTANCE && (!partials || !stats)) return PM_EINVAL;
   if (B == 0) return PM_OK;
   if (L < k) return PM_EINVAL;
-  if (C0 % 8 || C0 > 512) return PM_EUNSUPPORTED;
+  if (C0 % 8 || C0 > 512 || k != 10) return PM_EUNSUPPORTED;
   if ((uintptr_t)out & 15) return PM_EALIGN;
   const int64_t T0 = (L - k) / stride + 1;
   const int64_t nchunk = (T0 + TCH - 1) / TCH;
@@ -252,19 +287,19 @@ extern "C" int pm_w2v_stem0(const float* x, const float* w, const float* bias, i
   dim3 grid((unsigned)nchunk, (unsigned)B);
   int rc;
   if (norm == PM_W2V_NORM_INSTANCE) {
-    rc = launch_stem0<MODE_STATS>((int)k, grid, st, x, w, bias, nullptr, nullptr, nullptr, partials, eps, nullptr, L, (int)T0,
-                                  (int)C0, (int)stride, (int)nchunk);
-    if (rc != PM_OK) return rc;
-    hipLaunchKernelGGL(w2v_stats_finalize_kernel, dim3((unsigned)((B * C0 + 255) / 256)), dim3(256), 0, st, partials, stats,
-                       B * C0, (int)C0, (int)nchunk, (int)T0, eps);
-    rc = launch_stem0<MODE_INSTANCE>((int)k, grid, st, x, w, bias, gamma, beta, stats, nullptr, eps, (bf16*)out, L, (int)T0,
-                                     (int)C0, (int)stride, (int)nchunk);
+    const int na = (int)((T0 + ACH - 1) / ACH);
+    hipLaunchKernelGGL((w2v_autocorr_kernel<10>), dim3((unsigned)na, (unsigned)B), dim3(256), 0, st, x, partials, L, (int)T0,
+                       (int)stride, na);
+    hipLaunchKernelGGL((w2v_stats_finalize_kernel<10>), dim3((unsigned)B), dim3(256), 0, st, partials, w, bias, stats, (int)C0, na,
+                       (int)T0, eps);
+    rc = launch_stem0<MODE_INSTANCE>((int)k, grid, st, x, w, bias, gamma, beta, stats, eps, (bf16*)out, L, (int)T0, (int)C0,
+                                     (int)stride);
   } else if (norm == PM_W2V_NORM_LAYER) {
-    rc = launch_stem0<MODE_LAYERNORM>((int)k, grid, st, x, w, bias, gamma, beta, nullptr, nullptr, eps, (bf16*)out, L, (int)T0,
-                                      (int)C0, (int)stride, (int)nchunk);
+    rc = launch_stem0<MODE_LAYERNORM>((int)k, grid, st, x, w, bias, gamma, beta, nullptr, eps, (bf16*)out, L, (int)T0, (int)C0,
+                                      (int)stride);
   } else {
-    rc = launch_stem0<MODE_NONE>((int)k, grid, st, x, w, bias, nullptr, nullptr, nullptr, nullptr, eps, (bf16*)out, L, (int)T0,
-                                 (int)C0, (int)stride, (int)nchunk);
+    rc = launch_stem0<MODE_NONE>((int)k, grid, st, x, w, bias, nullptr, nullptr, nullptr, eps, (bf16*)out, L, (int)T0, (int)C0,
+                                 (int)stride);
   }
   if (rc != PM_OK) return rc;
   PM_CHECK_LAUNCH();

@@ -248,10 +248,10 @@ def w2v_stem0(x: Tensor, w: Tensor, bias: Tensor | None, norm: str, gamma: Tenso
     out = torch.empty((B, T0, C0), dtype=torch.bfloat16, device=x.device)
     partials = stats = None
     if mode == 2:
-        partials = torch.empty((B, int(lib().pm_w2v_stem0_chunks(T0)), C0, 2), dtype=torch.float32, device=x.device)
+        partials = torch.empty(int(lib().pm_w2v_stem0_scratch_floats(B, T0)), dtype=torch.float32, device=x.device)
         stats = torch.empty((B, C0, 2), dtype=torch.float32, device=x.device)
     ptr = lambda t: t.data_ptr() if t is not None else None
-    rc = _launch("w2v_stem0", float(B * T0 * C0 * 2 + B * L * 4 * (2 if mode == 2 else 1)), lambda: lib().pm_w2v_stem0(
+    rc = _launch("w2v_stem0", float(B * T0 * C0 * 2 + B * L * 4), lambda: lib().pm_w2v_stem0(
         x.data_ptr(), w.data_ptr(), ptr(bias), mode, ptr(gamma), ptr(beta), float(eps), ptr(partials), ptr(stats),
         out.data_ptr(), B, L, C0, k, stride, _stream()))
     check(rc, f"pm_w2v_stem0(B={B}, L={L}, C0={C0}, k={k}, norm={norm})")
