@@ -82,6 +82,14 @@ int pm_layernorm_ex(const void* x, int64_t ldx, int x_dtype, const float* gamma,
                     const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype, int64_t M,
                     int64_t d, void* stream);
 
+/* T5's LayerNorm (text/t5.py:15-25): y = x * rsqrt(mean(x^2) + eps) * gamma - no centring, no bias; fp32 statistics. */
+int pm_rmsnorm(const void* x, int64_t ldx, int x_dtype, const float* gamma, float eps, void* y, int64_t ldy, int y_dtype,
+               int64_t M, int64_t d, void* stream);
+
+/* The gate of GEGLU (text/t5.py:29-38) over a packed projection h = x [w; v]^T, bf16 (M, 2F) with row stride ldh:
+ * out[m, f] = gelu_tanh(h[m, f]) * h[m, F + f], bf16 (M, F).  F % 8 == 0. */
+int pm_geglu(const void* h, int64_t ldh, void* out, int64_t ldo, int64_t M, int64_t F, void* stream);
+
 /* ---- Wav2Vec2 / Data2VecAudio / SEW (audio/wav2vec2.py, audio/data2vec_audio.py, audio/sew.py).
  * All feature-encoder activations are (clip, time, channel) bf16, so Conv1d(C, C', k, stride s) over them is
  * pm_linear_bf16_ex with row stride s*C and K = k*C (weight K order (tap, channel)).
@@ -191,7 +199,8 @@ int pm_whisper_stem1(const float* x, const void* w, const float* bias, void* out
                      int64_t T, int64_t d, void* stream);
 
 /* nn.Embedding + positional add (whisper.py:48-49): out[b, l, :] = emb[tokens[b, l], :] + pos[pos0 + l, :].
- * tokens: int64 (B, L); emb: bf16 (V, d); pos: f32 (>= pos0 + L, d); out: bf16 | f32 (B, L, d). */
+ * tokens: int64 (B, L); emb: bf16 (V, d); pos: f32 (>= pos0 + L, d) or NULL (no absolute positions: text/t5.py:145);
+ * out: bf16 | f32 (B, L, d). */
 int pm_embed_tokens(const int64_t* tokens, const void* emb, const float* pos, void* out, int out_dtype, int64_t B,
                     int64_t L, int64_t pos0, int64_t d, int64_t V, void* stream);
 

@@ -17,8 +17,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   const int l = (int)(row % L) + pos0;
   for (int c = lane; c < d / 8; c += 64) {
     const bf16x8 e = *(const bf16x8*)(E + t * d + c * 8);
-    const f32x4 p0 = *(const f32x4*)(pos + (int64_t)l * d + c * 8);
-    const f32x4 p1 = *(const f32x4*)(pos + (int64_t)l * d + c * 8 + 4);
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+    if (pos) {  // no absolute positions: T5 (text/t5.py:145)
+      p0 = *(const f32x4*)(pos + (int64_t)l * d + c * 8);
+      p1 = *(const f32x4*)(pos + (int64_t)l * d + c * 8 + 4);
+    }
     float v[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = (float)e[i] + p0[i]; v[4 + i] = (float)e[4 + i] + p1[i]; }
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 
 extern "C" int pm_embed_tokens(const int64_t* tokens, const void* emb, const float* pos, void* out, int out_dtype,
                                int64_t B, int64_t L, int64_t pos0, int64_t d, int64_t V, void* stream) {
-  if (!tokens || !emb || !pos || !out || B < 0 || L < 0 || d <= 0 || V <= 0 || pos0 < 0) return PM_EINVAL;
+  if (!tokens || !emb || !out || B < 0 || L < 0 || d <= 0 || V <= 0 || pos0 < 0) return PM_EINVAL;
   if (B == 0 || L == 0) return PM_OK;
   if (d % 8) return PM_EUNSUPPORTED;
   if (((uintptr_t)emb | (uintptr_t)pos | (uintptr_t)out) & 15) return PM_EALIGN;

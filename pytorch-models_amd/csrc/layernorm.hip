@@ -43,7 +43,7 @@ template <bool XF32, bool YF32, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, void* __restrict__ y, int64_t ldy, int64_t M, int d,
-                                                        int act, const void* __restrict__ resid, int64_t ldr, int resid_f32) {
+                                                        int act, const void* __restrict__ resid, int64_t ldr, int resid_f32, int rms) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     }
   }
   const float inv_d = 1.0f / (float)d;
-  const float mean = wave_sum(s) * inv_d;
+  const float mean = rms ? 0.f : wave_sum(s) * inv_d;  // rms: no centring (T5's LayerNorm, text/t5.py:15-25)
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -80,9 +80,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
       float g[8], b[8];
       if (gamma) {  // elementwise_affine=False (data2vec_audio.py:27) passes null
         load8<true>(gamma, ch * 8, g);
-        load8<true>(beta, ch * 8, b);
+        if (beta) {
+          load8<true>(beta, ch * 8, b);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[c][i] = fmaf(v[c][i] * rstd, g[i], b[i]);
+          for (int i = 0; i < 8; ++i) v[c][i] = fmaf(v[c][i] * rstd, g[i], b[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[c][i] = v[c][i] * rstd * g[i];
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[c][i] *= rstd;
@@ -104,10 +109,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 
 template <bool XF32, bool YF32>
 void launch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t ldx, const float* g, const float* b, float eps,
-            void* y, int64_t ldy, int64_t M, int d, int act, const void* resid, int64_t ldr, int resid_f32) {
+            void* y, int64_t ldy, int64_t M, int d, int act, const void* resid, int64_t ldr, int resid_f32, int rms) {
 #define PM_LN(N)                                                                                                       \
   hipLaunchKernelGGL((layernorm_kernel<XF32, YF32, N>), grid, dim3(256), 0, st, x, ldx, g, b, eps, y, ldy, M, d, act, \
-                     resid, ldr, resid_f32);                                                                           \
+                     resid, ldr, resid_f32, rms);                                                                      \
   break
   switch (nch) {
     case 1: PM_LN(1);
@@ -122,10 +127,10 @@ void launch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t ldx, cons
 }  // namespace
 
 // y = act(LayerNorm(x)) + resid; gamma / beta both null = no affine; act in {NONE, GELU}; resid null = none.
-extern "C" int pm_layernorm_ex(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps,
-                               int act, const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype,
-                               int64_t M, int64_t d, void* stream) {
-  if (!x || !y || M < 0 || d <= 0 || ((gamma == nullptr) != (beta == nullptr))) return PM_EINVAL;
+static int layernorm_impl(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps, int act,
+                          const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype, int64_t M,
+                          int64_t d, int rms, void* stream) {
+  if (!x || !y || M < 0 || d <= 0 || (!rms && (gamma == nullptr) != (beta == nullptr)) || (rms && (!gamma || beta))) return PM_EINVAL;
   if ((x_dtype != PM_BF16 && x_dtype != PM_F32) || (y_dtype != PM_BF16 && y_dtype != PM_F32)) return PM_EINVAL;
   if (act != PM_ACT_NONE && act != PM_ACT_GELU) return PM_EUNSUPPORTED;
   if (resid && resid_dtype != PM_BF16 && resid_dtype != PM_F32) return PM_EINVAL;
@@ -141,16 +146,57 @@ extern "C" int pm_layernorm_ex(const void* x, int64_t ldx, int x_dtype, const fl
   hipStream_t st = (hipStream_t)stream;
   const bool xf = x_dtype == PM_F32, yf = y_dtype == PM_F32;
   const int rf = resid_dtype == PM_F32;
-  if (xf && yf) launch<true, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
-  else if (xf) launch<true, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
-  else if (yf) launch<false, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
-  else launch<false, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf);
+  if (xf && yf) launch<true, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf, rms);
+  else if (xf) launch<true, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf, rms);
+  else if (yf) launch<false, true>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf, rms);
+  else launch<false, false>(nch, grid, st, x, ldx, gamma, beta, eps, y, ldy, M, (int)d, act, resid, ldr, rf, rms);
   PM_CHECK_LAUNCH();
   return PM_OK;
+}
+
+extern "C" int pm_layernorm_ex(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps,
+                               int act, const void* resid, int64_t ldr, int resid_dtype, void* y, int64_t ldy, int y_dtype,
+                               int64_t M, int64_t d, void* stream) {
+  return layernorm_impl(x, ldx, x_dtype, gamma, beta, eps, act, resid, ldr, resid_dtype, y, ldy, y_dtype, M, d, 0, stream);
 }
 
 extern "C" int pm_layernorm(const void* x, int64_t ldx, int x_dtype, const float* gamma, const float* beta, float eps,
                             void* y, int64_t ldy, int y_dtype, int64_t M, int64_t d, void* stream) {
   if (!gamma || !beta) return PM_EINVAL;
-  return pm_layernorm_ex(x, ldx, x_dtype, gamma, beta, eps, PM_ACT_NONE, nullptr, 0, PM_BF16, y, ldy, y_dtype, M, d, stream);
+  return layernorm_impl(x, ldx, x_dtype, gamma, beta, eps, PM_ACT_NONE, nullptr, 0, PM_BF16, y, ldy, y_dtype, M, d, 0, stream);
+}
+
+// y = x * rsqrt(mean(x^2) + eps) * gamma: LayerNorm without centring and without bias (text/t5.py:15-25)
+extern "C" int pm_rmsnorm(const void* x, int64_t ldx, int x_dtype, const float* gamma, float eps, void* y, int64_t ldy,
+                          int y_dtype, int64_t M, int64_t d, void* stream) {
+  return layernorm_impl(x, ldx, x_dtype, gamma, nullptr, eps, PM_ACT_NONE, nullptr, 0, PM_BF16, y, ldy, y_dtype, M, d, 1, stream);
+}
+
+namespace {
+// out[m, f] = gelu_tanh(h[m, f]) * h[m, F + f]: the gate of GEGLU (text/t5.py:29-38) over a packed [w; v] projection
+__global__ __launch_bounds__(256) void geglu_kernel(const bf16* __restrict__ h, int64_t ldh, bf16* __restrict__ out, int64_t ldo,
+                                                    int F8, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t m = i / F8;
+  const int c = (int)(i - m * F8);
+  const bf16x8 a = *(const bf16x8*)(h + m * ldh + c * 8), b = *(const bf16x8*)(h + m * ldh + (int64_t)F8 * 8 + c * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)(apply_act<PM_ACT_GELU_TANH, true>((float)a[e]) * (float)b[e]);
+  *(bf16x8*)(out + m * ldo + c * 8) = o;
+}
+}  // namespace
+
+extern "C" int pm_geglu(const void* h, int64_t ldh, void* out, int64_t ldo, int64_t M, int64_t F, void* stream) {
+  if (!h || !out || M < 0 || F <= 0 || ldh < 2 * F || ldo < F) return PM_EINVAL;
+  if (F % 8) return PM_EUNSUPPORTED;
+  if (ldh % 8 || ldo % 8 || (((uintptr_t)h | (uintptr_t)out) & 15)) return PM_EALIGN;
+  if (M == 0) return PM_OK;
+  const int64_t total = M * (F / 8);
+  if ((total + 255) / 256 > 0x7fffffff) return PM_EINVAL;
+  hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)h, ldh,
+                     (bf16*)out, ldo, (int)(F / 8), total);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
 }

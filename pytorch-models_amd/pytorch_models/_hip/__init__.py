@@ -44,6 +44,8 @@ SIGNATURES = {
     "pm_dec_next_token": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _l, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
     "pm_layernorm_ex": ([_p, _l, _i, _p, _p, _f, _i, _p, _l, _i, _p, _l, _i, _l, _l, _p], c_int),
+    "pm_rmsnorm": ([_p, _l, _i, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
+    "pm_geglu": ([_p, _l, _p, _l, _l, _l, _p], c_int),
     "pm_w2v_stem0_scratch_floats": ([_l, _l], c_int64),
     "pm_w2v_stem0": ([_p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_group_windows": ([_p, _l, _i, _p, _l, _l, _l, _l, _l, _l, _l, _p], c_int),

@@ -135,6 +135,30 @@ def layernorm(x: Tensor, gamma: Tensor | None, beta: Tensor | None, eps: float, 
     return out
 
 
+def rmsnorm(x: Tensor, gamma: Tensor, eps: float, out_dtype: torch.dtype | None = None) -> Tensor:
+    """pm_rmsnorm: x (M, d) bf16 | f32 -> x * rsqrt(mean(x^2) + eps) * gamma (f32 gamma)."""
+    _cuda(x, gamma)
+    _need(x.dim() == 2 and x.stride(1) == 1, "rmsnorm: x must be (M, d), row-major")
+    M, d = x.shape
+    _need(gamma.dtype == torch.float32 and gamma.numel() == d, "rmsnorm: gamma must be f32 (d)")
+    out = torch.empty((M, d), dtype=out_dtype or x.dtype, device=x.device)
+    rc = _launch("layernorm", float(M * d * (x.element_size() + out.element_size())), lambda: lib().pm_rmsnorm(
+        x.data_ptr(), x.stride(0), _dt(x), gamma.data_ptr(), float(eps), out.data_ptr(), out.stride(0), _dt(out), M, d, _stream()))
+    check(rc, f"pm_rmsnorm(M={M}, d={d})")
+    return out
+
+
+def geglu(h: Tensor) -> Tensor:
+    """pm_geglu: bf16 (M, 2F) -> (M, F) = gelu_tanh(h[:, :F]) * h[:, F:]."""
+    _cuda(h)
+    _need(h.dim() == 2 and h.dtype == torch.bfloat16 and h.stride(1) == 1 and h.shape[1] % 2 == 0, "geglu: bf16 (M, 2F) rows")
+    M, F = h.shape[0], h.shape[1] // 2
+    out = torch.empty((M, F), dtype=torch.bfloat16, device=h.device)
+    rc = _launch("geglu", float(M * F * 6), lambda: lib().pm_geglu(h.data_ptr(), h.stride(0), out.data_ptr(), out.stride(0), M, F, _stream()))
+    check(rc, f"pm_geglu(M={M}, F={F})")
+    return out
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = False, bias: Tensor | None = None) -> Tensor:
     """q (B, Lq, H*hd), k / v (B, Lk, H*hd) bf16 views with unit last stride (e.g. column slices of a packed
     QKV projection) -> (B, Lq, H*hd) bf16, heads already merged.  bias: optional additive f32 (b, h, Lq, Lk) with
@@ -379,18 +403,19 @@ def whisper_stem1(x: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
     return out
 
 
-def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor, pos0: int = 0, out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
-    """tokens int64 (B, L) -> (B, L, d): emb[tokens] + pos[pos0 : pos0 + L]."""
+def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor | None, pos0: int = 0, out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """tokens int64 (B, L) -> (B, L, d): emb[tokens] + pos[pos0 : pos0 + L] (pos None: no positional term)."""
     _cuda(tokens, emb, pos)
     _need(tokens.dim() == 2 and tokens.dtype == torch.int64, "embed_tokens: tokens must be int64 (B, L)")
     tokens = tokens.contiguous()
     B, L = tokens.shape
     V, d = emb.shape
     _need(emb.dtype == torch.bfloat16 and emb.is_contiguous(), "embed_tokens: emb bf16 (V, d)")
-    _need(pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == d and pos.shape[0] >= pos0 + L,
-          f"embed_tokens: need {pos0 + L} position rows, have {pos.shape[0]}")
+    if pos is not None:
+        _need(pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == d and pos.shape[0] >= pos0 + L,
+              f"embed_tokens: need {pos0 + L} position rows, have {pos.shape[0]}")
     out = torch.empty((B, L, d), dtype=out_dtype, device=emb.device)
-    rc = lib().pm_embed_tokens(tokens.data_ptr(), emb.data_ptr(), pos.data_ptr(), out.data_ptr(), _dt(out), B, L, pos0, d, V,
+    rc = lib().pm_embed_tokens(tokens.data_ptr(), emb.data_ptr(), pos.data_ptr() if pos is not None else None, out.data_ptr(), _dt(out), B, L, pos0, d, V,
                                _stream())
     check(rc, f"pm_embed_tokens(B={B}, L={L}, d={d})")
     return out

@@ -256,6 +256,36 @@ def hf_wav2vec2(kind, n_layers, d, dims, kernels, *, legacy: bool, stem_bias: bo
     return sd
 
 
+def t5x_flat(n_layers, dim, n_heads, mlp_dim, vocab, seed=0):
+    """Flattened t5x ``target`` tree of a T5 v1.1 model (numpy, kernels stored (in, out), as the reference's
+    load_t5x_checkpoint returns it - text/t5.py:255-318)."""
+    inner = n_heads * 64
+    sd = {}
+
+    def put(k, shape):
+        sd[k] = _t(k, shape, seed).numpy()
+
+    put("token_embedder.embedding", (vocab, dim))
+    put("decoder.logits_dense.kernel", (dim, vocab))
+    for side, attns in (("encoder", (("attention", "pre_attention_layer_norm"),)),
+                        ("decoder", (("self_attention", "pre_self_attention_layer_norm"),
+                                     ("encoder_decoder_attention", "pre_cross_attention_layer_norm")))):
+        put(f"{side}.relpos_bias.rel_embedding", (n_heads, 32))
+        put(f"{side}.{side}_norm.scale", (dim,))
+        for i in range(n_layers):
+            b = f"{side}.layers_{i}."
+            for attn, norm in attns:
+                put(b + norm + ".scale", (dim,))
+                for nm in ("query", "key", "value"):
+                    put(b + attn + f".{nm}.kernel", (dim, inner))
+                put(b + attn + ".out.kernel", (inner, dim))
+            put(b + "pre_mlp_layer_norm.scale", (dim,))
+            put(b + "mlp.wi_0.kernel", (dim, mlp_dim))
+            put(b + "mlp.wi_1.kernel", (dim, mlp_dim))
+            put(b + "mlp.wo.kernel", (mlp_dim, dim))
+    return sd
+
+
 def state_digest(sd) -> dict:
     """name -> [sum, sum |x|, position-weighted sum] (fp64) of every tensor of a loaded model."""
     out = {}

@@ -406,9 +406,67 @@ def g_audio_enc():
     print("audio_converters.json", os.path.getsize(os.path.join(HERE, "audio_converters.json")) // 1024, "KiB")
 
 
+def g_t5():
+    """T5 v1.1 blocks at the shapes of the reference's own tests (tests/text/test_t5.py:10-16: dim 512, 6 heads of 64 -
+    inner width 384 != dim -, mlp 1024; 2 layers here), batched and unbatched, the greedy loop of T5Generator.generate
+    on token ids, and a digest of what the reference's inline t5x conversion (t5.py:169-178) makes of a synthetic
+    flattened t5x checkpoint."""
+    from pytorch_models.text import T5Decoder, T5Encoder, T5Model
+    from pytorch_models.text.t5 import _rename_key
+
+    sys.path.insert(2, os.path.join(ROOT, "tests"))
+    import ckpt_synth as C
+
+    dim, n_heads, n_layers, mlp_dim = 512, 6, 2, 1024
+    out = {}
+    x = synth_input("t5_x", (2, 64, dim), 91)
+    mem = synth_input("t5_mem", (2, 32, dim), 91)
+    m = T5Encoder(dim, n_heads, n_layers, mlp_dim).eval()
+    fill_module(m, 92)
+    out["encoder"] = m(x)[..., ::4]
+    out["encoder_unbatched"] = m(x[0])[..., ::4]
+    m = T5Decoder(dim, n_heads, n_layers, mlp_dim).eval()
+    fill_module(m, 93)
+    out["decoder"] = m(x, mem)[..., ::4]
+    m = T5Model(2000, dim, n_heads, n_layers, mlp_dim).eval()
+    fill_module(m, 94)
+    tok = synth_tokens("t5_tok", (2, 64), 1000, 95)
+    tgt = synth_tokens("t5_tgt", (2, 32), 1000, 95)
+    lg = m(tok, tgt)
+    out["model_logits_s7"], out["model_argmax"], out["model_digest"] = lg[..., ::7], lg.argmax(-1), digest(lg)
+    # T5Generator.generate's loop (t5.py:213-227) on ids: pad id 0 first, arg-max of the last position, stop at eos id 1
+    ids = [0]
+    memory = m.encode(tok[0])
+    while len(ids) < 12:
+        ids.append(m.decode(torch.tensor(ids), memory).argmax(-1)[-1].item())
+        if ids[-1] == 1:
+            break
+    out["greedy"] = np.array(ids)
+    rp = m.encoder.attn_bias
+    rp.bias.copy_(torch.arange(32, dtype=torch.float32).expand(n_heads, 32))  # bias value == bucket id
+    for L in (8, 64, 200):
+        out[f"buckets_bi_{L}"] = rp(L, True)[0].to(torch.int8)
+        out[f"buckets_uni_{L}"] = rp(L, False)[0].to(torch.int8)
+    # the reference converts a t5x checkpoint inline in from_t5x (needs the network); the same statements on a synthetic one
+    ckpt = C.t5x_flat(2, 128, 2, 256, 500, seed=96)
+    sd = {}
+    for k, v in ckpt.items():
+        v = torch.from_numpy(v)
+        if k.endswith("kernel"):
+            v = v.T
+        if k.endswith(("query.kernel", "key.kernel")):
+            v = v * 64**0.25
+        sd[_rename_key(k)] = v
+    m = T5Model(500, 128, 2, 2, 256)
+    m.load_state_dict(sd)
+    with open(os.path.join(HERE, "t5_converter.json"), "w") as f:
+        json.dump(C.state_digest(m.state_dict()), f, indent=0, sort_keys=True)
+    save("t5", dict(dim=dim), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters", "text", "audio_enc"]
+    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters", "text", "audio_enc", "t5"]
     table = dict(blocks=g_blocks, mha=g_mha, sdpa=g_sdpa_alignment, vit=g_vit, audio=g_audio, whisper=g_whisper,
-                 geometry=g_geometry, converters=g_converters, text=g_text, audio_enc=g_audio_enc)
+                 geometry=g_geometry, converters=g_converters, text=g_text, audio_enc=g_audio_enc, t5=g_t5)
     for w in which:
         table[w]()
