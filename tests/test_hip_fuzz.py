@@ -146,3 +146,52 @@ def test_encoder_layernorm_fold_random_geometries(d, L, B, seed):
     assert rel < 1e-2 and torch.isfinite(got.float()).all(), rel
     perm = torch.randperm(B, device="cuda", generator=g)
     torch.testing.assert_close(m(x[perm]), got[perm], rtol=0, atol=0)
+
+
+def _gc_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        cg = rng.choice([4, 8, 12, 16, 28, 32, 44, 48, 60, 64])
+        G = rng.choice([1, 2, 3, 16])
+        k = rng.choice([1, 2, 3, 19, 31, 64, 128])
+        stride = rng.choice([1, 1, 2, 3])
+        T = rng.randint(max(1, k // 2), 700)
+        pl = rng.randint(0, k)
+        pr = max(0, k - pl - T) + rng.randint(0, k)
+        out.append((rng.randint(1, 3), T, G, cg, k, stride, pl, pr, rng.choice(["none", "gelu"]), rng.random() < 0.5, rng.random() < 0.7))
+    return out
+
+
+@pytest.mark.parametrize("case", _gc_cases(40, 4321), ids=lambda c: "B{}-T{}-G{}-cg{}-k{}-s{}-p{}_{}-{}".format(*c[:9]))
+def test_grouped_conv_random_shapes(case):
+    """pm_group_windows + pm_grouped_conv_bf16 over random (clips, steps, groups, channels per group, taps, stride, padding):
+    both tile heights (64 and 256 steps), ragged last tiles, the zero-weighted K padding, every channel-chunk count."""
+    from pytorch_models._hip import ops
+
+    B, T, G, cg, k, stride, pl, pr, act, with_resid, with_bias = case
+    d = G * cg
+    g = torch.Generator().manual_seed(T * 13 + cg * 5 + k)
+    h = torch.randn(B, T, d, generator=g).to(torch.bfloat16)
+    w = (torch.randn(d, cg, k, generator=g) / math.sqrt(cg * k)).to(torch.bfloat16)
+    b = torch.randn(d, generator=g) * 0.1 if with_bias else None
+    Tp = T + pl + pr
+    To = (Tp - k) // stride + 1
+    r = torch.randn(B * To, d, generator=g).to(torch.bfloat16) if with_resid else None
+    cgp = (cg + 7) // 8 * 8
+    Kp = (k * cgp + 63) // 64 * 64
+    wk = torch.zeros(G, cg, k, cgp, dtype=torch.bfloat16)
+    wk[..., :cg] = w.view(G, cg, cg, k).permute(0, 1, 3, 2)
+    wp = torch.zeros(G, cg, Kp, dtype=torch.bfloat16)
+    wp[..., : k * cgp] = wk.view(G, cg, k * cgp)
+    xg = ops.group_windows(h.cuda(), G, cgp, pl, pr)
+    got = ops.grouped_conv(xg, wp.cuda(), None if b is None else b.cuda(), k, stride, cg, act, None if r is None else r.cuda())
+    hp = torch.nn.functional.pad(h.float().transpose(1, 2), (pl, pr))
+    want = torch.nn.functional.conv1d(hp, w.float(), b, stride=stride, groups=G).transpose(1, 2).reshape(B * To, d)
+    if act == "gelu":
+        want = RT.activation(want, "gelu")
+    if r is not None:
+        want = want + r.float()
+    assert got.shape == want.shape and torch.isfinite(got.float()).all()
+    err = (got.float().cpu() - want).abs()
+    assert (err <= 1e-2 * want.abs() + 1e-2 * want.pow(2).mean().sqrt()).all(), err.max().item()
