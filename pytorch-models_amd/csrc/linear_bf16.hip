@@ -10,6 +10,8 @@
 // the LDS side of global_load_lds is lane-linear.  The MFMA is issued with the WEIGHT tile as the A
 // operand and the token tile as B, so an accumulator lane holds 4 consecutive features of one token:
 // the epilogue packs them into one 8-byte (bf16) or 16-byte (f32) store.
+#include <stdlib.h>
+
 #include "common.h"
 // Priority: waves 4-7 (the younger wave of each SIMD pair, which loses every age-based arbitration and made waves 0-3
 // wait ~600-1200 cycles at each barrier) run at s_setprio 1 for the whole kernel; no per-step flips
@@ -488,6 +490,32 @@ int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int6
 
 }  // namespace
 
+// ---- which of the three kernels: a wave-quantisation cost model fitted to a sweep of transformer-block shapes
+// (tools/dispatch_sweep.py, 96 shapes: mean regret 0.2 %, worst 7 %; the tile-count thresholds it replaces - wide from 1024
+// tiles, 256 x 128 from 512 - left 7.8 % on the table, mostly at M = 6 k .. 32 k where a 256 x 256 tiling already fills the
+// chip).  Cost = rounds over the resident workgroups x work per tile / relative rate: 256 x 256 tiles on 256 workgroups at
+// 1.25, 256 x 128 on 256 at 1.0, 128 x 128 on 512 (two per CU) at 0.7 with a partly filled last round costing
+// 0.3 + 0.7 * fill of a full one (co-resident workgroups speed up when their neighbour has finished).
+enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3 };
+static int pm_linear_pick_kernel(int64_t M, int64_t N, bool persist_ok, bool wide_ok) {
+  static const int forced = [] { const char* e = getenv("PM_GEMM_KERNEL"); return e ? atoi(e) : 0; }();  // experiments: 1 / 2 / 3
+  if (forced == PM_K_WIDE && wide_ok) return PM_K_WIDE;
+  if (forced == PM_K_PERSIST && persist_ok) return PM_K_PERSIST;
+  if (forced == PM_K_SMALL) return PM_K_SMALL;
+  if (forced == PM_K_PERSIST) wide_ok = false;  // "no wider than": lets a sweep see each kernel's own curve
+  const double tm = (double)((M + 255) / 256), tw = tm * (double)((N + 255) / 256), tp = tm * (double)((N + 127) / 128);
+  const double ts = (double)((M + 127) / 128) * (double)((N + 127) / 128);
+  auto rounds = [](double t, double slots, double frac) {
+    const double full = (double)(int64_t)(t / slots), rem = t - full * slots;
+    return full + (rem > 0 ? frac + (1.0 - frac) * rem / slots : 0.0);
+  };
+  const double cs = rounds(ts, 512, 0.3) * 2.0 / 0.7;
+  const double cp = persist_ok ? rounds(tp, 256, 1.0) * 2.0 : 1e30;
+  const double cw = wide_ok ? rounds(tw, 256, 1.0) * 4.0 / 1.25 : 1e30;
+  if (cw <= cp && cw <= cs) return PM_K_WIDE;
+  return cp <= cs ? PM_K_PERSIST : PM_K_SMALL;
+}
+
 static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                        int64_t ldw, const float* bias, const void* resid, int64_t ldr, int resid_dtype,
                        int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
@@ -508,22 +536,29 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
                      !(resid && ((uintptr_t)resid & (resid_dtype == PM_F32 ? 15 : 7)));
   if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || resid_period > (1 << 30)) return PM_EINVAL;
   hipStream_t st0 = (hipStream_t)stream;
-  if (y_dtype == PM_BF16 && vec_ok && N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15) && !(resid && resid_dtype != PM_BF16) &&
-      !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) && pm_linear_bf16_wide_applies(M, N, K, act) &&
-      // the wide kernel keeps 32-bit element offsets per operand
-      (x_rows_per_batch > 0 ? (M / x_rows_per_batch + 1) * x_batch_stride : M * ldx) < (1LL << 32) && N * ldw < (1LL << 32)) {
-    if (ln.row_out) return PM_EUNSUPPORTED;  // row partials are produced by the 256 x 128 kernel (N = d_model layers)
+  const bool out_vec16 = N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15);
+  bool wide_ok = y_dtype == PM_BF16 && vec_ok && out_vec16 && !(resid && resid_dtype != PM_BF16) &&
+                 !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) && pm_linear_bf16_wide_applies(M, N, K, act) && !ln.row_out &&
+                 // the wide kernel keeps 32-bit element offsets per operand
+                 (x_rows_per_batch > 0 ? (M / x_rows_per_batch + 1) * x_batch_stride : M * ldx) < (1LL << 32) && N * ldw < (1LL << 32);
+  const bool persist_ok = (K % BK == 0) && (M >= 4096) && (y_dtype == PM_F32 || !vec_ok || out_vec16);
+  const bool staged_ok = persist_ok && y_dtype == PM_BF16 && vec_ok && !(resid && resid_dtype == PM_F32);
+  int kernel;
+  if (want_ln) {  // the LayerNorm fold lives in the persistent kernels' staged epilogues (row partials: 256 x 128 only)
+    if (!staged_ok) return PM_EUNSUPPORTED;
+    kernel = pm_linear_pick_kernel(M, N, true, wide_ok);
+    if (kernel == PM_K_SMALL) kernel = PM_K_PERSIST;
+  } else {
+    kernel = pm_linear_pick_kernel(M, N, persist_ok, wide_ok);
+  }
+  if (kernel == PM_K_WIDE) {
     const int rcw = pm_linear_bf16_wide_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
                                                ldy, M, N, K, act, ln, st0);
     if (rcw != PM_OK) return rcw;
     PM_CHECK_LAUNCH();
     return PM_OK;
   }
-  // 256 x 128 tiles (deep LDS ring, one workgroup per CU) once there are enough of them to fill the chip a few times
-  const bool big = (K % BK == 0) && (M >= 4096) && ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512 &&
-                   (y_dtype == PM_F32 || !vec_ok || (N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15)));
-  const bool staged = big && y_dtype == PM_BF16 && vec_ok && !(resid && resid_dtype == PM_F32);
-  if (want_ln && !staged) return PM_EUNSUPPORTED;  // the LayerNorm fold lives in the persistent kernels' staged epilogue
+  const bool big = kernel == PM_K_PERSIST;
   const int tiles_m = (int)((M + (big ? LBM : BM) - 1) / (big ? LBM : BM)), tiles_n = (int)((N + BN - 1) / BN);
   const int64_t nblk = (int64_t)tiles_m * tiles_n;
   if (nblk > 0x7fffffff) return PM_EINVAL;
@@ -602,9 +637,10 @@ extern "C" int pm_ln_stats_finalize(const float* row_partials, float* stats, int
 /* 1 if pm_linear_bf16_ln can serve this shape (as a consumer of ln_stats when produce == 0, as a producer of
  * ln_row_out when produce == 1), else 0: callers fall back to pm_layernorm + pm_linear_bf16. */
 extern "C" int pm_linear_ln_supported(int64_t M, int64_t N, int64_t K, int act, int produce) {
+  // shapes on which the fold is served AND worth it: a persistent kernel must be at least three quarters of a round full
+  // (below that the forced 256 x 128 tiling costs more than the LayerNorm launch it saves)
   if (K % 64 || N % 8 || M < 4096) return 0;
-  const bool wide = pm_linear_bf16_wide_applies(M, N, K, act);
-  const bool big = ((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) >= 512;
-  if (produce) return (!wide && big && N % 64 == 0) ? 1 : 0;
-  return (wide || big) ? 1 : 0;
+  if (((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) < 192) return 0;
+  if (produce) return N % 64 == 0 ? 1 : 0;
+  return 1;
 }

@@ -272,9 +272,9 @@ int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_ba
 }
 
 bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act) {
+  // shape eligibility only; whether the 256 x 256 tiling is the FASTEST of the three kernels is decided by the cost
+  // model of linear_impl (pm_linear_pick_kernel)
   if (act != PM_ACT_NONE && act != PM_ACT_GELU) return false;
   if (K % WBK || N % 8) return false;
-  const int64_t tiles = ((M + WBM - 1) / WBM) * ((N + WBN - 1) / WBN);
-  static const int64_t min_tiles = [] { const char* e = getenv("PM_WIDE_MIN_TILES"); return e ? atoll(e) : 1024LL; }();
-  return M >= 4096 && tiles >= min_tiles;  // >= 4 tiles per persistent workgroup: the 256 x 256 tail stays below ~10 %
+  return M >= 4096;
 }

@@ -91,10 +91,14 @@ class WhisperDecoder(nn.Module):
 
 
 class Whisper(nn.Module):
-    def __init__(self, vocab_size: int, n_layers: int, d_model: int, n_mels: int = 80, dropout: float = 0.0) -> None:
+    def __init__(self, vocab_size: int, n_layers: int, d_model: int, n_mels: int = 80, dropout: float = 0.0, *,
+                 n_decoder_layers: int | None = None) -> None:
+        """``n_decoder_layers`` (superset of the reference signature): a shallower decoder than encoder, the geometry of
+        the distilled checkpoints the reference lists as TODO (README.md:87; e.g. distil-large-v2 = 32 encoder / 2 decoder
+        layers).  Parameter names are unchanged, so such a checkpoint loads through load_openai_state_dict."""
         super().__init__()
         self.encoder = WhisperEncoder(n_layers, d_model, n_mels, dropout=dropout)
-        self.decoder = WhisperDecoder(vocab_size, n_layers, d_model, dropout=dropout)
+        self.decoder = WhisperDecoder(vocab_size, n_layers if n_decoder_layers is None else n_decoder_layers, d_model, dropout=dropout)
 
     def forward(self, x: Tensor, targets: Tensor) -> Tensor:
         return self.decoder(targets, self.encoder(x))

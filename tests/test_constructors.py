@@ -120,3 +120,11 @@ def test_mel_filters_match_reference_golden(golden):
     g = golden("audio")
     torch.testing.assert_close(get_mel_filters(80, 400, 16000), g["filters80"], rtol=1e-4, atol=5e-7)
     torch.testing.assert_close(get_mel_filters(128, 400, 16000), g["filters128"], rtol=1e-4, atol=5e-7)
+
+
+def test_whisper_shallow_decoder_keeps_parameter_names():
+    from pytorch_models.audio2text import Whisper
+
+    full, distil = Whisper(100, 3, 64), Whisper(100, 3, 64, n_decoder_layers=1)
+    assert len(distil.encoder.layers) == 3 and len(distil.decoder.layers) == 1
+    assert set(distil.state_dict()) < set(full.state_dict())  # a strict subset: the decoder layers that are gone

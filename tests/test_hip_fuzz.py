@@ -35,7 +35,23 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(70, 1234), ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}-{c[3]}-{c[4]}-{'f32' if c[5] == torch.float32 else 'bf16'}")
+def _mid_cases(n, seed):
+    """M = 4 k .. 24 k, where the dispatcher's cost model moves between the three kernels (partly filled persistent rounds,
+    persistent workgroups without a tile)."""
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        M = rng.randint(4096, 24000)
+        N = rng.choice([48, 256, 512, 768, 1024, 1536, 2048, 2304, 3072, 4096, 1000])
+        K = 64 * rng.randint(1, 16)
+        act = rng.choice(["none", "none", "gelu", "relu"])
+        resid = rng.choice([None, "bf16", "f32"])
+        odt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float32])
+        out.append((M, N, K, act, resid, odt, rng.random() < 0.7))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(70, 1234) + _mid_cases(30, 99), ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}-{c[3]}-{c[4]}-{'f32' if c[5] == torch.float32 else 'bf16'}")
 def test_linear_random_shapes(case):
     from pytorch_models._hip import ops
 

@@ -165,3 +165,26 @@ def test_whisper_128_mel_path_end_to_end():
     for b in range(2):
         diff = (toks[b] != want[b]).nonzero()
         assert not len(diff) or float(margins[b, int(diff[0]) - 3]) < 2e-4
+
+
+def test_distilled_geometry_shallow_decoder():
+    """Distilled Whisper (README.md:87 of the reference: TODO): 4 encoder layers, 1 decoder layer.  Teacher-forced logits
+    and 8 greedy ids against the oracle on the same bf16-rounded weights."""
+    from pytorch_models.audio2text import Whisper
+
+    w, sd = hip_and_sd(Whisper(1000, 4, 128, n_decoder_layers=1), 58)
+    assert len(w.encoder.layers) == 4 and len(w.decoder.layers) == 1
+    mel = synth_input("w_mel_distil", (2, 80, 200), 58)
+    toks = synth_tokens("w_tok_distil", (2, 7), 1000, 58)
+    logits = w(mel.cuda(), toks.cuda())
+    assert rel_l2(logits, RW.forward(sd, mel, toks)) < 3e-2
+    memory = w.encoder(mel.cuda())
+    ids = w.decoder.generate(memory, toks[:, :3].cuda(), 8).cpu()
+
+    def kv_round(name, t):
+        return t.to(torch.bfloat16).float() if name == "kv" else t
+
+    want, margins = RW.greedy_cached(sd, "decoder.", toks[:, :3], memory.float().cpu(), 8, rp=kv_round)
+    for b in range(2):
+        diff = (ids[b] != want[b]).nonzero()
+        assert not len(diff) or float(margins[b, int(diff[0]) - 3]) < 2e-4
