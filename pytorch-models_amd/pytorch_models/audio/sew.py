@@ -17,6 +17,7 @@ class SEW(Wav2Vec2):
     STEM_STRIDES = (5,) + (2, 1) * 6
 
     PE_KERNEL = 31
+    _HF_FLAVOUR = "sew"  # projection keys without the feature_projection prefix, plus encoder.upsample (sew.py:55-79)
 
     def __init__(self, n_layers: int, d_model: int, stem_bias: bool = True, stem_legacy: bool = True, dropout: float = 0.0) -> None:
         assert stem_legacy
@@ -37,13 +38,3 @@ class SEW(Wav2Vec2):
         if y.shape[1] < T:  # odd T: the dropped last frame comes back as zeros (sew.py:37-38)
             y = torch.cat([y, y.new_zeros(B, T - y.shape[1], d)], 1)
         return y.to(self.norm.weight.dtype)
-
-    @torch.no_grad()
-    def load_hf_state_dict(self, state_dict: dict[str, Tensor]) -> None:
-        sd = dict(state_dict)
-        self._load_stem_and_layers(sd, "layer_norm", "feature_projection")
-        self._load_weight_normed_pe(sd)
-        up = self.upsample[0]
-        up.weight.copy_(sd.pop("encoder.upsample.projection.weight"))
-        up.bias.copy_(sd.pop("encoder.upsample.projection.bias"))
-        print(sd.keys())

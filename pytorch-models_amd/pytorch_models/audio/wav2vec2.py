@@ -109,11 +109,7 @@ class Wav2Vec2(nn.Module):
     def __init__(self, n_layers: int, d_model: int, stem_bias: bool = True, stem_legacy: bool = False, dropout: float = 0.0,
                  pre_norm: bool = True) -> None:
         super().__init__()
-        self.feature_encoder = FeatureEncoder(self.STEM_DIMS, self.STEM_KERNELS, self.STEM_STRIDES, stem_bias, dropout, stem_legacy)
-        in_dim = self.STEM_DIMS[-1]
-        self.proj = nn.Sequential(LayerNorm(in_dim))
-        if in_dim != d_model:
-            self.proj.append(Linear(in_dim, d_model))
+        self._front(d_model, stem_bias, stem_legacy, dropout)
         self.pe_conv = nn.Sequential(
             nn.ConstantPad1d((self.PE_KERNEL // 2, self.PE_KERNEL // 2 - 1), 0),  # "same" padding for an even kernel
             nn.Conv1d(d_model, d_model, self.PE_KERNEL, groups=self.PE_GROUPS),
@@ -122,6 +118,13 @@ class Wav2Vec2(nn.Module):
         self.layers = Encoder(n_layers, d_model, dropout=dropout, pre_norm=pre_norm)
         self.norm = LayerNorm(d_model)
         self.pre_norm = pre_norm
+
+    def _front(self, d_model: int, stem_bias: bool, stem_legacy: bool, dropout: float) -> None:
+        """feature_encoder + proj, shared by the three model classes: conv stem over the waveform, LayerNorm over its channels
+        and - only when the widths differ - a Linear onto d_model (wav2vec2.py:62-68)."""
+        self.feature_encoder = FeatureEncoder(self.STEM_DIMS, self.STEM_KERNELS, self.STEM_STRIDES, stem_bias, dropout, stem_legacy)
+        stem_out = self.STEM_DIMS[-1]
+        self.proj = nn.Sequential(LayerNorm(stem_out), *([Linear(stem_out, d_model)] if stem_out != d_model else []))
 
     # ---- grouped positional conv: pm_group_windows + pm_grouped_conv_bf16 (input span resident in LDS)
     @staticmethod
@@ -195,42 +198,12 @@ class Wav2Vec2(nn.Module):
             _kwargs["pre_norm"] = config["do_stable_layer_norm"]
         return cls(**_kwargs, **kwargs)
 
-    # ---- HF checkpoint names (wav2vec2.py:113-152)
-    def _load_stem_and_layers(self, sd: dict, proj_ln: str, proj_lin: str) -> None:
-        def copy_w(module, prefix: str):
-            module.weight.copy_(sd.pop(f"{prefix}.weight"))
-            if module.bias is not None:
-                module.bias.copy_(sd.pop(f"{prefix}.bias"))
+    _HF_FLAVOUR = "wav2vec2"
 
-        for i, blk in enumerate(self.feature_encoder):
-            prefix = f"feature_extractor.conv_layers.{i}"
-            copy_w(blk[0], f"{prefix}.conv")
-            if not isinstance(blk[2], nn.Identity):
-                copy_w(blk[2], f"{prefix}.layer_norm")
-        copy_w(self.proj[0], proj_ln)
-        if len(self.proj) > 1:
-            copy_w(self.proj[1], proj_lin)
-        copy_w(self.norm, "encoder.layer_norm")
-        for i, layer in enumerate(self.layers):
-            prefix = f"encoder.layers.{i}"
-            for ours, theirs in (("q_proj", "attention.q_proj"), ("k_proj", "attention.k_proj"), ("v_proj", "attention.v_proj"),
-                                 ("out_proj", "attention.out_proj")):
-                copy_w(getattr(layer.sa, ours), f"{prefix}.{theirs}")
-            copy_w(layer.sa_norm, f"{prefix}.layer_norm")
-            copy_w(layer.mlp.linear1, f"{prefix}.feed_forward.intermediate_dense")
-            copy_w(layer.mlp.linear2, f"{prefix}.feed_forward.output_dense")
-            copy_w(layer.mlp_norm, f"{prefix}.final_layer_norm")
-
-    def _load_weight_normed_pe(self, sd: dict) -> None:
-        # torch.nn.utils.weight_norm(dim=2) undone: w = g * v / ||v|| with the norm over (out, in) per tap
-        prefix = "encoder.pos_conv_embed.conv"
-        g, v = sd.pop(f"{prefix}.weight_g"), sd.pop(f"{prefix}.weight_v")
-        self.pe_conv[1].weight.copy_(g * v / v.float().pow(2).sum((0, 1), keepdim=True).sqrt().clamp_min(1e-12).to(v.dtype))
-        self.pe_conv[1].bias.copy_(sd.pop(f"{prefix}.bias"))
-
-    @torch.no_grad()
     def load_hf_state_dict(self, state_dict: dict[str, Tensor]) -> None:
-        sd = dict(state_dict)
-        self._load_stem_and_layers(sd, "feature_projection.layer_norm", "feature_projection.projection")
-        self._load_weight_normed_pe(sd)
-        print(sd.keys())
+        """Hugging Face Wav2Vec2Model / HubertModel (Data2VecAudioModel, SEWModel in the subclasses) state_dict, keys without the
+        model prefix (wav2vec2.py:113-152; converters.load_hf_wav2vec2).  Prints the keys it did not use, like the reference."""
+        from ..converters import load_hf_wav2vec2
+
+        left = load_hf_wav2vec2(self, state_dict, flavour=self._HF_FLAVOUR)
+        print(dict.fromkeys(left).keys())

@@ -45,31 +45,8 @@ class BERT(nn.Module):
             f"BERT.from_hf({model_tag!r}) fetches config.json (and weights) from the network, which this build does not do; "
             "use BERT.from_config(json.load(open('config.json'))) and load_hf_state_dict(torch.load(path, weights_only=True)).")
 
-    @torch.no_grad()
     def load_hf_state_dict(self, state_dict: dict[str, Tensor]) -> None:
-        """Hugging Face BertModel / RobertaModel state_dict; placement as bert.py:79-107."""
-        is_roberta = any(k.startswith("roberta.") for k in state_dict)
-        sd = {k.removeprefix("bert.").removeprefix("roberta."): v for k, v in state_dict.items()}
+        """Hugging Face BertModel / RobertaModel state_dict (converters.load_hf_bert; placement as bert.py:79-107)."""
+        from ..converters import load_hf_bert
 
-        def put(module, prefix: str) -> None:
-            module.weight.copy_(sd.pop(f"{prefix}.weight"))
-            if module.bias is not None:
-                module.bias.copy_(sd.pop(f"{prefix}.bias"))
-
-        wte = sd.pop("embeddings.word_embeddings.weight")
-        self.token_embs.weight[: wte.shape[0]] = wte
-        pos = sd.pop("embeddings.position_embeddings.weight")
-        if is_roberta:
-            pos = pos[2:]
-        self.pos_embs.copy_(pos + sd.pop("embeddings.token_type_embeddings.weight")[0])
-        put(self.norm, "embeddings.LayerNorm")
-        for i, layer in enumerate(self.layers):
-            p = f"encoder.layer.{i}"
-            put(layer.sa.q_proj, f"{p}.attention.self.query")
-            put(layer.sa.k_proj, f"{p}.attention.self.key")
-            put(layer.sa.v_proj, f"{p}.attention.self.value")
-            put(layer.sa.out_proj, f"{p}.attention.output.dense")
-            put(layer.sa_norm, f"{p}.attention.output.LayerNorm")
-            put(layer.mlp.linear1, f"{p}.intermediate.dense")
-            put(layer.mlp.linear2, f"{p}.output.dense")
-            put(layer.mlp_norm, f"{p}.output.LayerNorm")
+        load_hf_bert(self, state_dict)

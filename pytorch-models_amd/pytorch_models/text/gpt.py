@@ -32,26 +32,9 @@ class GPT(nn.Module):
                 "pretrained=False and call load_openai_params(list of arrays in params_shapes.json order).")
         return m
 
-    @torch.no_grad()
     def load_openai_params(self, params) -> None:
-        """The flat parameter list of openai/finetune-transformer-lm (pos, tokens, then 12 tensors per layer), already
-        split and reshaped as gpt.py:40-52 does; placement as gpt.py:54-84."""
-        params = [torch.as_tensor(p) for p in params]
-        self.pos_embs.copy_(params[0])
-        self.token_embs.weight[: params[1].shape[0]] = params[1]
-        n = 12
-        for i, layer in enumerate(self.layers):
-            q = params[2 + i * n: 2 + (i + 1) * n]
-            for proj, w, b in zip((layer.sa.q_proj, layer.sa.k_proj, layer.sa.v_proj), q[0].squeeze(0).chunk(3, -1), q[1].chunk(3, -1)):
-                proj.weight.copy_(w.T)
-                proj.bias.copy_(b)
-            layer.sa.out_proj.weight.copy_(q[2].squeeze(0).T)
-            layer.sa.out_proj.bias.copy_(q[3])
-            layer.sa_norm.weight.copy_(q[4])
-            layer.sa_norm.bias.copy_(q[5])
-            layer.mlp.linear1.weight.copy_(q[6].squeeze(0).T)
-            layer.mlp.linear1.bias.copy_(q[7])
-            layer.mlp.linear2.weight.copy_(q[8].squeeze(0).T)
-            layer.mlp.linear2.bias.copy_(q[9])
-            layer.mlp_norm.weight.copy_(q[10])
-            layer.mlp_norm.bias.copy_(q[11])
+        """The flat parameter list of openai/finetune-transformer-lm, already split and reshaped as gpt.py:40-52 does
+        (converters.load_openai_gpt; placement as gpt.py:54-84)."""
+        from ..converters import load_openai_gpt
+
+        load_openai_gpt(self, params)

@@ -60,29 +60,8 @@ class GPT2(nn.Module):
                 "pretrained=False and call load_hf_state_dict(torch.load(path, weights_only=True)).")
         return m
 
-    @torch.no_grad()
     def load_hf_state_dict(self, state_dict: dict[str, Tensor]) -> None:
-        """Hugging Face GPT2LMHeadModel state_dict (Conv1D weights are (in, out): transposed here; c_attn split in three)."""
-        sd = {k.removeprefix("transformer."): v for k, v in state_dict.items()}
+        """Hugging Face GPT2LMHeadModel state_dict (converters.load_hf_gpt2)."""
+        from ..converters import load_hf_gpt2
 
-        def put(module, prefix: str) -> None:
-            w = sd.pop(f"{prefix}.weight")
-            module.weight.copy_(w.T if w.ndim == 2 else w)
-            if module.bias is not None:
-                module.bias.copy_(sd.pop(f"{prefix}.bias"))
-
-        wte = sd.pop("wte.weight")
-        self.token_embs.weight[: wte.shape[0]] = wte
-        self.pos_embs.copy_(sd.pop("wpe.weight"))
-        for i, layer in enumerate(self.layers):
-            p = f"h.{i}"
-            put(layer.sa_norm, f"{p}.ln_1")
-            put(layer.sa.out_proj, f"{p}.attn.c_proj")
-            for proj, w, b in zip((layer.sa.q_proj, layer.sa.k_proj, layer.sa.v_proj), sd.pop(f"{p}.attn.c_attn.weight").chunk(3, 1),
-                                  sd.pop(f"{p}.attn.c_attn.bias").chunk(3, 0)):
-                proj.weight.copy_(w.T)
-                proj.bias.copy_(b)
-            put(layer.mlp_norm, f"{p}.ln_2")
-            put(layer.mlp.linear1, f"{p}.mlp.c_fc")
-            put(layer.mlp.linear2, f"{p}.mlp.c_proj")
-        put(self.norm, "ln_f")
+        load_hf_gpt2(self, state_dict)
