@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--workload", default="vit", choices=["vit", "whisper"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the BASELINE config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--whisper-layers", type=int, default=0,
+                    help="whisper: layers per stack (0 = 8, the reference's \"base\"; 6 = OpenAI's base geometry, a labelled extra: SURVEY.md F2)")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL; "gloo" only to rehearse N > 1 on one GPU)')
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-graph", action="store_true", help="whisper: eager decode launches instead of the captured HIP graph "

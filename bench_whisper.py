@@ -49,6 +49,10 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
     B = args.batch or 32
     tag = "base"
     m = Whisper.from_openai(tag).eval()  # 8 layers, exactly as the reference builds "base" 
+    n_layers = len(m.encoder.layers)
+    if getattr(args, "whisper_layers", 0) and args.whisper_layers != n_layers:  # labelled extra, not the BASELINE config
+        n_layers = args.whisper_layers
+        m = Whisper(51865, n_layers, 512).eval()
     fill_module(m, 56)
     m = m.to(torch.bfloat16).to(device)
     pre = WhisperPreprocessor(tag).to(device)
@@ -91,7 +95,7 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
         "metric": "Whisper-base audio-sec/s (BASELINE.json: Whisper-base audio-sec/s & ViT-B/16 images/s)",
         "value": round(world * B * 30.0 * args.steps / dt, 1),
         "unit": "audio-s/s",
-        "config": {"workload": f"Whisper-base (reference geometry: 8 layers, d=512): log-mel + encoder + greedy decode "
+        "config": {"workload": f"Whisper-base ({'reference geometry: 8' if n_layers == 8 else 'EXTRA, not the BASELINE config: ' + str(n_layers)} layers, d=512): log-mel + encoder + greedy decode "
                                f"(prompt {PROMPT}, {N_NEW} new tokens, KV cache), 30 s synthetic audio, batch={B} per GPU "
                                "(BASELINE configs[2])",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
@@ -128,6 +132,6 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
         res["decode_kernels_eager_ms_per_step"] = {
             k: round(sum(a.elapsed_time(b) for a, b, _ in v) / (len(v) / sum(1 for f, _ in dec.launches if f.__name__ == k)), 4)
             for k, v in dlog.items()}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and n_layers == 8:  # the CPU leg is the BASELINE geometry's
             res["cpu_baseline"] = cpu_baseline_whisper(host_cores())
     return res
