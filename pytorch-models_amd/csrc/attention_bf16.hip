@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
 
   const bool wave_live = q0 + wave * 32 < Lq;
   const float* bias_row = BIAS ? bias + (int64_t)b * bsb + (int64_t)h * bsh + (int64_t)qi_ld * bsq : nullptr;
+  const bool bias_vec = BIAS && !(((uintptr_t)bias | (uintptr_t)(bsb * 4) | (uintptr_t)(bsh * 4) | (uintptr_t)(bsq * 4)) & 15);
   load_tile(0);
   write_tile(smem);
   __syncthreads();
@@ -132,6 +133,21 @@ _Pragma("unroll")                                                               
     const bool tail = (t + 1) * KV_TILE > Lk;                                                                            \
     const bool diag = CAUSAL && ((t + 1) * KV_TILE - 1 > q0 + wave * 32);                                                \
     float mx = -1e30f;                                                                                                   \
+    f32x4 bq[2][4];  /* this lane's 8 groups of 4 consecutive keys: 16-byte loads when the bias rows allow it */          \
+    if constexpr (BIAS) {                                                                                                \
+_Pragma("unroll")                                                                                                        \
+      for (int kb = 0; kb < 2; ++kb)                                                                                     \
+_Pragma("unroll")                                                                                                        \
+        for (int gq = 0; gq < 4; ++gq) {                                                                                 \
+          const int key = key_base + kb * 32 + 8 * gq;                                                                   \
+          if (bias_vec && key + 3 < Lk) {                                                                                \
+            bq[kb][gq] = *(const f32x4*)(bias_row + key);                                                                \
+          } else {                                                                                                       \
+_Pragma("unroll")                                                                                                        \
+            for (int e = 0; e < 4; ++e) bq[kb][gq][e] = key + e < Lk ? bias_row[key + e] : 0.f;                          \
+          }                                                                                                              \
+        }                                                                                                                \
+    }                                                                                                                    \
 _Pragma("unroll")                                                                                                        \
     for (int kb = 0; kb < 2; ++kb)                                                                                       \
 _Pragma("unroll")                                                                                                        \
@@ -139,8 +155,7 @@ _Pragma("unroll")                                                               
         if (kb == 1 && !kb1) continue;                                                                                   \
         float v = (MASKED) ? sc[kb][i] * c : sc[kb][i];  /* mask-free tiles keep RAW scores: max(c s) = c max(s) */      \
         if constexpr (BIAS) {  /* additive attn_bias[b, h, q, k] (strides may be 0 = broadcast), natural-log units */    \
-          const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);                                                   \
-          if (key < Lk) v = fmaf(bias_row[key], 1.4426950408889634f, v);                                                 \
+          v = fmaf(bq[kb][i >> 2][i & 3], 1.4426950408889634f, v);  /* keys past Lk carry 0 and are masked below */      \
         }                                                                                                                \
         if ((MASKED) && (tail || diag)) {                                                                                \
           const int key = key_base + kb * 32 + (i & 3) + 8 * (i >> 2);                                                   \
