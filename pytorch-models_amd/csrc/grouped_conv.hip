@@ -165,8 +165,12 @@ int launch_act(int act, dim3 grid, size_t lds, hipStream_t st, const bf16* xg, c
 #define PM_GC(A)                                                                                                             \
   do {                                                                                                                       \
     auto kern = grouped_conv_kernel<CPT, NJ, MI, A, SWZ>;                                                                    \
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)         \
-      return PM_ELAUNCH;                                                                                                     \
+    static int lds_allowed = 0; /* per instantiation: raise the dynamic-LDS limit once, outside any stream capture */       \
+    if ((int)lds > lds_allowed) {                                                                                            \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+        return PM_ELAUNCH;                                                                                                   \
+      lds_allowed = 160 * 1024;                                                                                              \
+    }                                                                                                                        \
     hipLaunchKernelGGL(kern, grid, dim3(GC_THREADS), lds, st, xg, w, bias, resid, ldr, y, ldy, G, Tp, To, cg, stride, Kp,   \
                        tiles_t, span_rows);                                                                                  \
   } while (0)

@@ -497,7 +497,7 @@ int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int6
 // 1.25, 256 x 128 on 256 at 1.0, 128 x 128 on 512 (two per CU) at 0.7 with a partly filled last round costing
 // 0.3 + 0.7 * fill of a full one (co-resident workgroups speed up when their neighbour has finished).
 enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3 };
-static int pm_linear_pick_kernel(int64_t M, int64_t N, bool persist_ok, bool wide_ok) {
+static int pm_linear_pick_kernel(int64_t M, int64_t N, bool persist_ok, bool wide_ok, bool has_resid) {
   static const int forced = [] { const char* e = getenv("PM_GEMM_KERNEL"); return e ? atoi(e) : 0; }();  // experiments: 1 / 2 / 3
   if (forced == PM_K_WIDE && wide_ok) return PM_K_WIDE;
   if (forced == PM_K_PERSIST && persist_ok) return PM_K_PERSIST;
@@ -509,9 +509,11 @@ static int pm_linear_pick_kernel(int64_t M, int64_t N, bool persist_ok, bool wid
     const double full = (double)(int64_t)(t / slots), rem = t - full * slots;
     return full + (rem > 0 ? frac + (1.0 - frac) * rem / slots : 0.0);
   };
-  const double cs = rounds(ts, 512, 0.3) * 2.0 / 0.7;
+  // with a residual operand in the epilogue the 256 x 256 tiling keeps less of its edge (second sweep, --resid: rates 1.1 and
+  // 0.65 pick within 0.1 % of the best kernel, worst case 3 %)
+  const double cs = rounds(ts, 512, 0.3) * 2.0 / (has_resid ? 0.65 : 0.7);
   const double cp = persist_ok ? rounds(tp, 256, 1.0) * 2.0 : 1e30;
-  const double cw = wide_ok ? rounds(tw, 256, 1.0) * 4.0 / 1.25 : 1e30;
+  const double cw = wide_ok ? rounds(tw, 256, 1.0) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
   if (cw <= cp && cw <= cs) return PM_K_WIDE;
   return cp <= cs ? PM_K_PERSIST : PM_K_SMALL;
 }
@@ -546,10 +548,10 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   int kernel;
   if (want_ln) {  // the LayerNorm fold lives in the persistent kernels' staged epilogues (row partials: 256 x 128 only)
     if (!staged_ok) return PM_EUNSUPPORTED;
-    kernel = pm_linear_pick_kernel(M, N, true, wide_ok);
+    kernel = pm_linear_pick_kernel(M, N, true, wide_ok, resid != nullptr);
     if (kernel == PM_K_SMALL) kernel = PM_K_PERSIST;
   } else {
-    kernel = pm_linear_pick_kernel(M, N, persist_ok, wide_ok);
+    kernel = pm_linear_pick_kernel(M, N, persist_ok, wide_ok, resid != nullptr);
   }
   if (kernel == PM_K_WIDE) {
     const int rcw = pm_linear_bf16_wide_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,

@@ -211,3 +211,22 @@ def test_wav2vec2_base_geometry_10s_clip():
     y = m(x.cuda())
     assert y.shape == (2, 499, 768)
     assert rel(y[:1], RA.wav2vec2(sd, x[:1], pre_norm=False, legacy=True)) < 2e-2
+
+
+def test_graphed_forward_replays_the_eager_launches():
+    """pytorch_models.graph.GraphedForward: one captured HIP graph gives bit-identical outputs to the eager forward, also on
+    new input contents; shape changes are refused."""
+    from pytorch_models.audio import Wav2Vec2
+    from pytorch_models.graph import GraphedForward
+
+    m, _ = prep(Wav2Vec2(2, 128, stem_bias=False, stem_legacy=True, pre_norm=False), 83)
+    x1 = synth_input("w2v_x", (2, 6400), 81).cuda()
+    x2 = synth_input("w2v_x2", (2, 6400), 82).cuda()
+    g = GraphedForward(m, x1)
+    assert torch.equal(g(x1), m(x1))
+    assert torch.equal(g(x2), m(x2))
+    assert torch.equal(g(x1), m(x1))
+    with pytest.raises(ValueError, match="captured for"):
+        g(x1[:, :3200])
+    with pytest.raises(RuntimeError, match="HIP device"):
+        GraphedForward(m, x1.cpu())

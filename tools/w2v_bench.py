@@ -40,6 +40,17 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 print(f"wav2vec2-{args.model} B={B} {args.seconds:g} s clips -> {tuple(y.shape)}: {dt * 1e3:8.2f} ms/step  "
       f"{B * args.seconds / dt:9.1f} audio-s/s", flush=True)
+from pytorch_models.graph import GraphedForward  # noqa: E402
+
+g = GraphedForward(m, x)
+g(x)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    g(x)
+torch.cuda.synchronize()
+dtg = (time.perf_counter() - t0) / args.steps
+print(f"  as one HIP graph (pytorch_models.graph.GraphedForward): {dtg * 1e3:8.2f} ms/step  {B * args.seconds / dtg:9.1f} audio-s/s", flush=True)
 ops.LAUNCH_LOG = {}
 m(x)
 torch.cuda.synchronize()
