@@ -452,7 +452,6 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   const int inner = H * 64;
   const int tpos = SELF ? *pos_ptr : 0;
   const int Lk = SELF ? tpos + 1 : lk_const;
-  const int nproj = SELF ? 3 : 1;
 
   // ---- projection weights: 8 lanes per output row, lane p owns 16-byte chunks p, p+8, ...
   const int prow = tid >> 3, pl = tid & 7;

@@ -174,7 +174,6 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
       __builtin_amdgcn_s_setprio(0);
 #endif
     }
-    const int cbuf = buf;
     buf = (buf + 1) & (WRING - 1);
     if (++kt < nk) continue;
 
