@@ -211,3 +211,65 @@ def test_grouped_conv_random_shapes(case):
     assert got.shape == want.shape and torch.isfinite(got.float()).all()
     err = (got.float().cpu() - want).abs()
     assert (err <= 1e-2 * want.abs() + 1e-2 * want.pow(2).mean().sqrt()).all(), err.max().item()
+
+
+def _row_cases(n, seed):
+    rng = random.Random(seed)
+    return [(rng.randint(1, 3000), 8 * rng.randint(1, 512), rng.choice([torch.bfloat16, torch.float32]), rng.choice([torch.bfloat16, torch.float32]),
+             rng.choice(["ln", "ln_noaffine", "rms"]), rng.choice(["none", "gelu"]), rng.choice([None, torch.bfloat16, torch.float32]))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _row_cases(30, 777), ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-{c[5]}")
+def test_row_norms_random_shapes(case):
+    """pm_layernorm / pm_layernorm_ex / pm_rmsnorm over random (rows, width <= 4096, dtypes, affine, activation, residual)."""
+    from pytorch_models._hip import ops
+
+    M, d, xdt, ydt, kind, act, rdt = case
+    g = torch.Generator().manual_seed(M * 31 + d)
+    x = (torch.randn(M, d, generator=g) * 1.5 + 0.3).to(xdt)
+    gamma, beta = torch.randn(d, generator=g) * 0.2 + 1.0, torch.randn(d, generator=g) * 0.1
+    xf = x.float()
+    if kind == "rms":
+        want = xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-5) * gamma
+        got = ops.rmsnorm(x.cuda(), gamma.cuda(), 1e-5, ydt)
+    else:
+        xc = xf - xf.mean(-1, keepdim=True)
+        want = xc * torch.rsqrt((xc * xc).mean(-1, keepdim=True) + 1e-5)
+        if kind == "ln":
+            want = want * gamma + beta
+        if act == "gelu":
+            want = RT.activation(want, "gelu")
+        r = None if rdt is None else torch.randn(M, d, generator=g).to(rdt)
+        if r is not None:
+            want = want + r.float()
+        got = ops.layernorm(x.cuda(), gamma.cuda() if kind == "ln" else None, beta.cuda() if kind == "ln" else None, 1e-5, ydt, act=act,
+                            resid=None if r is None else r.cuda())
+    assert got.dtype == ydt and got.shape == (M, d)
+    tol = dict(rtol=3e-5, atol=3e-5) if ydt == torch.float32 else dict(rtol=4e-3, atol=2e-3)
+    torch.testing.assert_close(got.float().cpu(), want, **tol)
+
+
+@pytest.mark.parametrize("case", [(1, 10, 8, "none"), (2, 400, 64, "instance"), (3, 16000, 512, "layer"), (1, 48000, 512, "instance"),
+                                  (5, 3333, 256, "layer"), (2, 1285, 24, "instance"), (4, 2561, 128, "none")],
+                         ids=lambda c: f"B{c[0]}-L{c[1]}-C{c[2]}-{c[3]}")
+def test_w2v_stem0_shapes(case):
+    """pm_w2v_stem0 across clip lengths (chunk boundaries of both passes), channel counts and norms, against conv1d in fp32."""
+    from pytorch_models._hip import ops
+
+    B, L, C0, norm = case
+    g = torch.Generator().manual_seed(L + C0)
+    x = torch.randn(B, L, generator=g) * 0.5 + 0.05
+    w = torch.randn(C0, 10, generator=g) / 3.0
+    b = torch.randn(C0, generator=g) * 0.1
+    gamma, beta = torch.randn(C0, generator=g) * 0.2 + 1.0, torch.randn(C0, generator=g) * 0.1
+    h = torch.nn.functional.conv1d(x[:, None], w[:, None], b, stride=5).transpose(1, 2)  # (B, T0, C0)
+    if norm == "layer":
+        h = torch.nn.functional.layer_norm(h, (C0,), gamma, beta, 1e-5)
+    elif norm == "instance":
+        hc = h - h.mean(1, keepdim=True)
+        h = hc * torch.rsqrt((hc * hc).mean(1, keepdim=True) + 1e-5) * gamma + beta
+    want = RT.activation(h, "gelu")
+    got = ops.w2v_stem0(x.cuda(), w.cuda(), b.cuda(), norm, gamma.cuda() if norm != "none" else None, beta.cuda() if norm != "none" else None,
+                        1e-5, 5)
+    torch.testing.assert_close(got.float().cpu(), want, rtol=4e-3, atol=2e-3)
