@@ -230,3 +230,20 @@ def test_graphed_forward_replays_the_eager_launches():
         g(x1[:, :3200])
     with pytest.raises(RuntimeError, match="HIP device"):
         GraphedForward(m, x1.cpu())
+
+
+def test_no_projection_when_stem_width_equals_d_model_and_fp32_sew():
+    """d_model = 512 = the stem's width: proj is the LayerNorm alone (wav2vec2.py:67-68), and the positional conv has 32
+    channels per group.  SEW left in fp32 (the reference's default) returns fp32 at the stem's frame rate."""
+    from pytorch_models.audio import SEW, Wav2Vec2
+
+    m, sd = prep(Wav2Vec2(1, 512), 87)
+    assert len(m.proj) == 1
+    x = synth_input("w2v_x", (2, 6400), 81)
+    y = m(x.cuda())
+    assert y.shape == (2, 19, 512) and rel(y, RA.wav2vec2(sd, x)) < 2e-2
+    s = SEW(2, 128)
+    fill_module(s, 85)
+    sd = {k: v.clone() for k, v in s.state_dict().items()}
+    ys = s.cuda().eval()(x.cuda())
+    assert ys.dtype == torch.float32 and ys.shape == (2, 19, 128) and rel(ys, RA.sew(sd, x)) < 3e-2
