@@ -128,3 +128,14 @@ def test_whisper_shallow_decoder_keeps_parameter_names():
     full, distil = Whisper(100, 3, 64), Whisper(100, 3, 64, n_decoder_layers=1)
     assert len(distil.encoder.layers) == 3 and len(distil.decoder.layers) == 1
     assert set(distil.state_dict()) < set(full.state_dict())  # a strict subset: the decoder layers that are gone
+
+
+def test_graphed_forward_refuses_cpu_inputs():
+    import torch
+
+    from pytorch_models.graph import GraphedForward
+
+    with pytest.raises(RuntimeError, match="HIP device"):
+        GraphedForward(torch.nn.Identity(), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        GraphedForward(torch.nn.Identity())
