@@ -32,6 +32,26 @@ __device__ __forceinline__ void stage_w(const bf16* __restrict__ W, int64_t ld, 
   }
 }
 
+// the same tile through registers (vit_tokens_kernel: its pixel loads are ordinary loads, and the compiler's wait insertion only
+// counts exactly when every vector-memory operation in flight is of one kind - with LDS-DMA in the mix it waits vmcnt(0))
+__device__ __forceinline__ void load_w(const bf16* __restrict__ W, int64_t ld, int row0, int row_max, int k0, int wave, int lane,
+                                       bf16x8 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rt = wave * 32 + i * 8 + (lane >> 3);
+    int grow = row0 + rt;
+    grow = grow < row_max ? grow : row_max - 1;
+    regs[i] = *(const bf16x8*)(W + (int64_t)grow * ld + k0 + (lane & 7) * 8);
+  }
+}
+__device__ __forceinline__ void write_w(char* tile, int wave, int lane, const bf16x8 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rt = wave * 32 + i * 8 + (lane >> 3);
+    *(bf16x8*)(tile + rt * 128 + swz_pos(rt, lane & 7) * 16) = regs[i];
+  }
+}
+
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int row, int chunk) {
   return *(const bf16x8*)(tile + row * 128 + swz_pos(row, chunk) * 16);
 }
@@ -63,24 +83,28 @@ __global__ __launch_bounds__(256, 2) void vit_tokens_kernel(const float* __restr
     const int gy = p / gw, gx = p - gy * gw;
     pix_base[hf] = (n * 3 * Himg + gy * P) * (int64_t)Wimg + gx * P + quarter * 4;
   }
-  f32x4 areg[8];
-  auto load_a = [&](int kt) {
+  // pixels travel two K steps ahead of their use (two register sets), the weight tile one step: when step kt ends, the pixel
+  // loads of step kt + 2 are the youngest vector-memory operations and stay in flight while the compiler's exact wait covers
+  // the weights and pixels of step kt + 1.  With one set and vmcnt(0) per step every step exposed a full HBM latency
+  // (1.4 TB/s of algorithmic bytes).
+  f32x4 areg[2][8];
+  auto load_a = [&](int kt, f32x4 (&regs)[8]) {
     const int k0 = kt * BK;
     const int c = k0 >> 8, ph0 = (k0 & 255) >> 4;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int ph = ph0 + (it >> 1);
-      areg[it] = *(const f32x4*)(imgs + pix_base[it & 1] + ((int64_t)c * Himg + ph) * Wimg);
+      regs[it] = *(const f32x4*)(imgs + pix_base[it & 1] + ((int64_t)c * Himg + ph) * Wimg);
     }
   };
-  auto write_a = [&](char* tile) {
+  auto write_a = [&](char* tile, const f32x4 (&regs)[8]) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = (tid >> 2) + (it & 1) * 64;
       const int chunk = 2 * (it >> 1) + (quarter >> 1);
       bf16x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (bf16)areg[it][j];
+      for (int j = 0; j < 4; ++j) v[j] = (bf16)regs[it][j];
       *(bf16x4*)(tile + row * 128 + swz_pos(row, chunk) * 16 + (quarter & 1) * 8) = v;
     }
   };
@@ -91,22 +115,28 @@ __global__ __launch_bounds__(256, 2) void vit_tokens_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
-  load_a(0);
-  stage_w(W, K, n0, d, 0, smem + TILE_BYTES, wave, lane);
-  write_a(smem);
-  wait_vmcnt0();
-  __syncthreads();
+  constexpr int nk = 3 * P * P / BK;  // 12, compile-time: the loop is fully unrolled so that the compiler's own waits for the pixel
+                                      // registers are exact counts (across a loop back-edge it falls back to vmcnt(0))
+  bf16x8 wreg[4];
+  load_a(0, areg[0]);
+  load_w(W, K, n0, d, 0, wave, lane, wreg);
+  load_a(1, areg[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  write_a(smem, areg[0]);
+  write_w(smem + TILE_BYTES, wave, lane, wreg);
+  // raw barrier: __syncthreads() carries a fence that waits for EVERY outstanding load (vmcnt(0)), the prefetch included
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
   const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
   for (int kt = 0; kt < nk; ++kt) {
     char* acur = smem + (kt & 1) * 2 * TILE_BYTES;
     char* wcur = acur + TILE_BYTES;
     char* anxt = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-    if (kt + 1 < nk) {
-      stage_w(W, K, n0, d, (kt + 1) * BK, anxt + TILE_BYTES, wave, lane);
-      load_a(kt + 1);
-    }
+    if (kt + 1 < nk) load_w(W, K, n0, d, (kt + 1) * BK, wave, lane, wreg);
+    if (kt + 2 < nk) load_a(kt + 2, areg[kt & 1]);  // the set that fed step kt (written to LDS one step ago)
+    __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks these loads down to their use, two steps later
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 a[4], b[4];
@@ -119,9 +149,12 @@ __global__ __launch_bounds__(256, 2) void vit_tokens_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
     }
-    if (kt + 1 < nk) write_a(anxt);
-    wait_vmcnt0();
-    __syncthreads();
+    if (kt + 1 < nk) {
+      write_a(anxt, areg[(kt + 1) & 1]);
+      write_w(anxt + TILE_BYTES, wave, lane, wreg);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 
   const int has_cls = cls != nullptr;
