@@ -10,8 +10,9 @@
 // one channel x 4 patch rows x 16 pixels, so a patch contributes four 64-byte pixel runs per step and
 // 16 consecutive patches of one image row contribute one contiguous 1 KiB run: a wave's float4 loads
 // (4 lanes per patch run, 16 patches) are full-line coalesced.  Pixels are converted to bf16 on the
-// way into the swizzled LDS tile; the weight tile streams in with global_load_lds exactly as in
-// linear_bf16.hip.
+// way into the swizzled LDS tile, two K steps after their loads were issued; the weight tile goes through
+// registers as well (see load_w: one kind of load in flight keeps the compiler's waits exact).  The
+// generic-patch kernel below keeps the simple single-buffered form with global_load_lds weights.
 #include "common.h"
 
 namespace {
