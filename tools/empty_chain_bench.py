@@ -1,5 +1,10 @@
-import os, sys
-sys.path[:0] = ["/root/repo", "/root/repo/pytorch-models_amd"]
+"""What does one more launch cost inside a replayed HIP graph?  A chain of N launches of a (nearly) empty kernel, graph-replayed:
+the per-launch floor the decode step is measured against (1.57 us).     python tools/empty_chain_bench.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-models_amd")]
 import torch
 from pytorch_models._hip import lib
 pos = torch.zeros(1, dtype=torch.int32, device="cuda")

@@ -1,5 +1,10 @@
+"""Per-kernel view of one GPT-2 small decode step (eager pass with HIP events, every 8th step sampled).
+    python tools/gpt2_decode_profile.py"""
+import os
 import sys
-sys.path[:0] = ["/root/repo", "/root/repo/pytorch-models_amd"]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-models_amd")]
 import torch
 from pytorch_models.text import GPT2
 from pytorch_models.audio2text.generate import GreedyDecoder
