@@ -263,6 +263,20 @@ int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_t
 /* ++*pos_ptr, as its own launch (every workgroup of the step has read t by then). */
 int pm_dec_advance(int32_t* pos_ptr, void* stream);
 
+/* Whisper's decoding-time logit filters on the device, between the vocabulary projection (pm_dec_linear mode 0 into logits) and
+ * the token choice (pm_dec_sample_topk; k = 1 = arg-max).  The reference has no Whisper decoding (README.md:86-87: TODO); the rules
+ * are those of OpenAI's whisper decoding.py (SuppressTokens, SuppressBlank, ApplyTimestampRules) as published - that package is
+ * not available here, so the oracle for this entry point (oracle/ref_whisper_rules.py) is "parity unpinned".
+ * logits: f32 (B, V), modified in place (-inf); tokens: int64 (B, Ttot) = prompt + generated; n = *pos_ptr + 1 is the index being
+ * chosen (nothing happens while n < P); eot < timestamp_begin < V; no_timestamps < 0 = none; max_initial_timestamp < 0 = no cap
+ * (else the first timestamp is at most timestamp_begin + max_initial_timestamp); suppress / blank: int32 id lists (blank applies
+ * to the first generated token only).  Rules: listed ids; a transcript starts with a timestamp; timestamps come in pairs and
+ * never decrease; if the timestamps' total probability exceeds the best text token's, text is masked. */
+int pm_dec_whisper_rules(float* logits, int64_t ldl, int64_t V, const int64_t* tokens, int64_t Ttot, const int32_t* pos_ptr,
+                         int64_t P, int64_t eot, int64_t no_timestamps, int64_t timestamp_begin, int64_t max_initial_timestamp,
+                         const int32_t* suppress, int64_t n_suppress, const int32_t* blank, int64_t n_blank, int64_t B,
+                         void* stream);
+
 /* Top-k sampling in place of the arg-max (text/generator.py:30-32: topk, softmax over the k logits, one multinomial draw):
  * logits (B, V) f32, row stride ldl, of the last position (pm_dec_linear mode 0 with the final LayerNorm); per sequence the
  * k (1..64) largest (ties: lowest index first), softmax over them, one draw from a counter-based generator keyed by

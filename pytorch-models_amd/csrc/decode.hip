@@ -715,6 +715,77 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
   }
 }
 
+// ---- Whisper's decoding-time logit filters, on the device, between the vocabulary projection and the token choice.
+// The reference has no Whisper decoding at all (README.md:86-87 lists tokenizer / timestamp handling as TODO); the rules
+// restated here are those of OpenAI's whisper (decoding.py: SuppressTokens, SuppressBlank, ApplyTimestampRules), taken from
+// its published description - that package is not in the image, so oracle/ref_whisper_rules.py is "parity unpinned".
+// One workgroup per sequence; n = *pos_ptr + 1 is the index of the token being chosen, generated tokens are ids[P .. n).
+//   always        : logits[suppress[i]] = -inf;  logits[no_timestamps] = -inf
+//   n == P        : logits[blank[i]] = -inf (no blank / end-of-text first); text tokens [0, ts_begin) = -inf (a transcript
+//                   starts with a timestamp); timestamps beyond ts_begin + max_initial are -inf
+//   pairing       : last token a timestamp -> if the one before was too (or there is none): timestamps [ts_begin, V) = -inf,
+//                   else (an open segment must be closed): text [0, eot) = -inf
+//   monotonic     : timestamps below the last emitted one (below or equal, unless that one still waits for its partner) = -inf
+//   probability   : if logsumexp(timestamp logits) > max(text logits): text [0, ts_begin) = -inf
+__global__ __launch_bounds__(DF_THREADS) void dec_whisper_rules_kernel(float* __restrict__ logits, int64_t ldl, int V,
+                                                               const int64_t* __restrict__ tokens, int Ttot,
+                                                               const int* __restrict__ pos_ptr, int P, int eot, int no_ts,
+                                                               int ts_begin, int max_initial, const int* __restrict__ suppress,
+                                                               int n_suppress, const int* __restrict__ blank, int n_blank) {
+  __shared__ float red[4 * DF_WAVES];
+  __shared__ int redi[DF_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = *pos_ptr + 1;
+  if (n < P) return;  // the prompt is still being forced
+  float* lg = logits + (int64_t)blockIdx.x * ldl;
+  const int64_t* ids = tokens + (int64_t)blockIdx.x * Ttot;
+  const int ngen = n - P;
+  const bool last_ts = ngen >= 1 && ids[n - 1] >= ts_begin;
+  const bool penult_ts = ngen < 2 || ids[n - 2] >= ts_begin;
+  // index of the last emitted timestamp (-1: none)
+  int li = -1;
+  for (int i = P + tid; i < n; i += DF_THREADS)
+    if (ids[i] >= ts_begin) li = i;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) li = max(li, __shfl_xor(li, o, 64));
+  if (lane == 0) redi[wave] = li;
+  __syncthreads();
+  li = redi[0];
+#pragma unroll
+  for (int w = 1; w < DF_WAVES; ++w) li = max(li, redi[w]);
+  int ts_floor = ts_begin;  // timestamps in [ts_begin, ts_floor) are forbidden
+  if (li >= 0) ts_floor = (int)ids[li] + ((last_ts && !penult_ts) ? 0 : 1);
+  const bool no_text_pair = last_ts && !penult_ts;  // text [0, eot) forbidden
+  const bool no_ts_pair = last_ts && penult_ts;     // every timestamp forbidden
+  const bool first = ngen == 0;
+  const int ts_cap = (first && max_initial >= 0) ? ts_begin + max_initial : V - 1;  // timestamps above are forbidden
+  for (int v = tid; v < V; v += DF_THREADS) {
+    bool dead = v == no_ts;
+    if (v < ts_begin) dead = dead || first || (no_text_pair && v < eot);
+    else dead = dead || no_ts_pair || v < ts_floor || v > ts_cap;
+    if (dead) lg[v] = -INFINITY;
+  }
+  for (int i = tid; i < n_suppress; i += DF_THREADS) lg[suppress[i]] = -INFINITY;
+  if (first)
+    for (int i = tid; i < n_blank; i += DF_THREADS) lg[blank[i]] = -INFINITY;
+  __syncthreads();
+  // statistics over the filtered row (the listed suppressions included): V floats from L2
+  float m_text = -INFINITY, m_ts = -INFINITY;
+  for (int v = tid; v < V; v += DF_THREADS) {
+    const float x = lg[v];
+    if (v < ts_begin) m_text = fmaxf(m_text, x);
+    else m_ts = fmaxf(m_ts, x);
+  }
+  m_text = block_reduce8(m_text, red, true);
+  m_ts = block_reduce8(m_ts, red + DF_WAVES, true);
+  if (m_ts == -INFINITY) return;  // no timestamp allowed at all: nothing to compare
+  float se = 0.f;
+  for (int v = ts_begin + tid; v < V; v += DF_THREADS) se += expf(lg[v] - m_ts);
+  se = block_reduce8(se, red + 2 * DF_WAVES, false);
+  if (m_ts + logf(se) > m_text)
+    for (int v = tid; v < ts_begin; v += DF_THREADS) lg[v] = -INFINITY;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Top-k sampling of the next token (the reference's text/generator.py:30-32: topk, softmax over the k logits,
 // multinomial), one workgroup per sequence: k rounds of a block-wide arg-max in the order (value descending, index
@@ -1057,6 +1128,20 @@ extern "C" int pm_dec_next_token(const float* ws_val, const int32_t* ws_idx, int
   hipLaunchKernelGGL(dec_argmax_reduce_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, ws_val,
                      (const int*)ws_idx, (int)n_tiles, (const int*)pos_ptr, prompt, (int)P, tok_cur, tokens_out, (int)Ttot,
                      margin_out, (const bf16*)emb, pos, x, (int)d, (int)V, (int*)ticket, (int*)pos_ptr);
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+extern "C" int pm_dec_whisper_rules(float* logits, int64_t ldl, int64_t V, const int64_t* tokens, int64_t Ttot,
+                                    const int32_t* pos_ptr, int64_t P, int64_t eot, int64_t no_timestamps,
+                                    int64_t timestamp_begin, int64_t max_initial_timestamp, const int32_t* suppress,
+                                    int64_t n_suppress, const int32_t* blank, int64_t n_blank, int64_t B, void* stream) {
+  if (!logits || !tokens || !pos_ptr || V <= 0 || ldl < V || P <= 0 || Ttot < P || B <= 0) return PM_EINVAL;
+  if (timestamp_begin <= 0 || timestamp_begin >= V || eot < 0 || eot >= timestamp_begin || no_timestamps >= V) return PM_EINVAL;
+  if ((n_suppress > 0 && !suppress) || (n_blank > 0 && !blank) || n_suppress < 0 || n_blank < 0) return PM_EINVAL;
+  hipLaunchKernelGGL(dec_whisper_rules_kernel, dim3((unsigned)B), dim3(DF_THREADS), 0, (hipStream_t)stream, logits, ldl, (int)V, tokens,
+                     (int)Ttot, (const int*)pos_ptr, (int)P, (int)eot, (int)no_timestamps, (int)timestamp_begin,
+                     (int)max_initial_timestamp, (const int*)suppress, (int)n_suppress, (const int*)blank, (int)n_blank);
   PM_CHECK_LAUNCH();
   return PM_OK;
 }

@@ -40,6 +40,7 @@ SIGNATURES = {
     "pm_dec_attention_fused": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p], c_int),
     "pm_dec_argmax_reduce": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _l, _p], c_int),
     "pm_dec_advance": ([_p, _p], c_int),
+    "pm_dec_whisper_rules": ([_p, _l, _l, _p, _l, _p, _l, _l, _l, _l, _l, _p, _l, _p, _l, _l, _p], c_int),
     "pm_dec_sample_topk": ([_p, _l, _l, _l, ctypes.c_uint64, _p, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p], c_int),
     "pm_dec_next_token": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _l, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),

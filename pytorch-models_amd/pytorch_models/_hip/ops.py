@@ -495,3 +495,22 @@ def dec_attention(q: Tensor, k: Tensor, v: Tensor, lk: int) -> Tensor:
                                 out.data_ptr(), B, H, _stream())
     check(rc, "pm_dec_attention")
     return out
+
+
+def dec_whisper_rules(logits: Tensor, tokens: Tensor, pos: Tensor, P: int, *, eot: int, timestamp_begin: int, no_timestamps: int = -1,
+                      max_initial_timestamp: int = -1, suppress=(), blank=()) -> Tensor:
+    """pm_dec_whisper_rules as a standalone op (the generator puts it into its launch list): filters logits (B, V) f32 IN PLACE for
+    the token at index pos + 1 of tokens (B, Ttot) int64; returns logits."""
+    _cuda(logits, tokens, pos)
+    _need(logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1, "dec_whisper_rules: logits f32 (B, V)")
+    _need(tokens.dim() == 2 and tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.shape[0] == logits.shape[0],
+          "dec_whisper_rules: tokens int64 (B, Ttot)")
+    _need(pos.dtype == torch.int32 and pos.numel() == 1, "dec_whisper_rules: pos is one device int32")
+    i32 = dict(dtype=torch.int32, device=logits.device)
+    sup, blk = torch.tensor(list(suppress), **i32), torch.tensor(list(blank), **i32)
+    B, V = logits.shape
+    rc = lib().pm_dec_whisper_rules(logits.data_ptr(), logits.stride(0), V, tokens.data_ptr(), tokens.shape[1], pos.data_ptr(), P, eot,
+                                    no_timestamps, timestamp_begin, max_initial_timestamp, sup.data_ptr() if sup.numel() else None,
+                                    sup.numel(), blk.data_ptr() if blk.numel() else None, blk.numel(), B, _stream())
+    check(rc, f"pm_dec_whisper_rules(B={B}, V={V})")
+    return logits

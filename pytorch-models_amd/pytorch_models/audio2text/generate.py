@@ -11,6 +11,7 @@ step is captured ONCE into a HIP graph and replayed - no tracing compiler, no ho
 from __future__ import annotations
 
 import os
+from dataclasses import dataclass
 
 import torch
 from torch import Tensor
@@ -23,11 +24,24 @@ def _ptr(t: Tensor | None):
     return None if t is None else t.data_ptr()
 
 
+@dataclass
+class WhisperRules:
+    """Whisper's decoding-time logit filters (pm_dec_whisper_rules): ids of the tokenizer in use.  ``blank`` = ids forbidden as
+    the first generated token (the blank token and end-of-text); ``max_initial_timestamp`` counts timestamp steps (0.02 s each)
+    from ``timestamp_begin``, < 0 = no cap."""
+    eot: int
+    timestamp_begin: int
+    no_timestamps: int = -1
+    max_initial_timestamp: int = -1
+    suppress: tuple = ()
+    blank: tuple = ()
+
+
 class GreedyDecoder:
     """State + launch list of the decode step for one (decoder, batch, memory length) geometry."""
 
     def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False, fused: bool = True,
-                 topk: int = 1, seed: int = 0) -> None:
+                 topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None) -> None:
         E = dec.token_embs.weight
         if E.dtype != torch.bfloat16 or not E.is_cuda:
             raise NotImplementedError("greedy decode: bf16 weights on a HIP device only (model.to(torch.bfloat16).cuda())")
@@ -184,7 +198,7 @@ class GreedyDecoder:
             add(L.pm_layernorm, self.x.data_ptr(), d, 1, g.data_ptr(), b.data_ptr(), float(dec.norm.eps), self.xn.data_ptr(), d, 1,
                 B, d, None)
             xl, gl, bl = self.xn, None, None
-        if topk == 1:
+        if topk == 1 and rules is None:
             dec_linear(xl, d, gl, bl, dec.norm.eps, E, None, None, None, V, mode=2, ldo=0)
             # token choice + the next step's embedding row + position advance: one launch
             add(L.pm_dec_next_token, self.ws_val.data_ptr(), self.ws_idx.data_ptr(), n_tiles, self.pos.data_ptr(),
@@ -195,6 +209,16 @@ class GreedyDecoder:
                 raise ValueError("greedy decode: margins are an arg-max diagnostic (topk == 1)")
             self.logits = torch.empty(B, V, **f32)
             dec_linear(xl, d, gl, bl, dec.norm.eps, E, None, None, self.logits, V, mode=0)
+            if rules is not None:  # logit filters between the projection and the choice (k = 1 below = arg-max)
+                i32 = dict(dtype=torch.int32, device=dev)
+                sup, blk = torch.tensor(list(rules.suppress), **i32), torch.tensor(list(rules.blank), **i32)
+                if not (0 <= rules.eot < rules.timestamp_begin < V) or any(not 0 <= int(i) < V for i in (*rules.suppress, *rules.blank)):
+                    raise ValueError("WhisperRules: need 0 <= eot < timestamp_begin < vocab and listed ids inside the vocabulary")
+                self._keep += [sup, blk]
+                add(L.pm_dec_whisper_rules, self.logits.data_ptr(), self.logits.stride(0), V, self.tokens.data_ptr(), self.Ttot,
+                    self.pos.data_ptr(), P, rules.eot, rules.no_timestamps, rules.timestamp_begin, rules.max_initial_timestamp,
+                    sup.data_ptr() if sup.numel() else None, sup.numel(), blk.data_ptr() if blk.numel() else None, blk.numel(),
+                    B, None)
             add(L.pm_dec_sample_topk, self.logits.data_ptr(), self.logits.stride(0), V, topk, int(seed) & (2**64 - 1),
                 self.pos.data_ptr(), self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot,
                 E.data_ptr(), pos_f32.data_ptr(), self.x.data_ptr(), d, self.ticket.data_ptr(), B, None)
@@ -257,10 +281,10 @@ class GreedyDecoder:
 
 @torch.no_grad()
 def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: bool = True, margins: bool = False,
-                  fused: bool = True, topk: int = 1, seed: int = 0):
+                  fused: bool = True, topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None):
     """tokens (B, P + n_new) int64 [and per-position diagnostic margins].  fused=False uses the unfused
     projection + attention launches (same arithmetic, 2 more launches per layer); topk > 1 samples each token from the
     softmax over the k largest logits on the device (same seed -> same ids)."""
-    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused, topk, seed)
+    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused, topk, seed, rules)
     toks = st.run(graph)
     return (toks, st.margins) if margins else toks
