@@ -188,6 +188,15 @@ int pm_stft_mel(const float* x, int64_t x_stride, int64_t B, int64_t T, const fl
                 int64_t n_fft, int64_t hop, int64_t n_frames, int mode, const int32_t* mel_ptr, const int32_t* mel_col,
                 const float* mel_val, int64_t n_mels, float* out, int32_t* peak, void* stream);
 
+/* pm_stft_mel for a SYMMETRIC window (w[k] == w[n_fft - k], k = 1 .. n_fft - 1: every Hann / Hamming ...): the frame is folded
+ * about n_fft / 2 - cosine terms on x[k] + x[n_fft - k], sine terms on x[k] - x[n_fft - k] - which halves the contraction.
+ * Tables laid out [ceil(nbins / 32)][S][64] with S = (n_fft / 2 + 2) / 2 and k = 2 s + (lane >> 5): cosine entries for
+ * k = 0 .. n_fft / 2 (the k = n_fft / 2 entry HALVED, it meets its own mirror), sine entries for k = 1 .. n_fft / 2 - 1, zero
+ * elsewhere.  Everything else as pm_stft_mel. */
+int pm_stft_mel_folded(const float* x, int64_t x_stride, int64_t B, int64_t T, const float* tw_cos, const float* tw_sin,
+                       int64_t n_fft, int64_t hop, int64_t n_frames, int mode, const int32_t* mel_ptr, const int32_t* mel_col,
+                       const float* mel_val, int64_t n_mels, float* out, int32_t* peak, void* stream);
+
 /* whisper.py:146-147 in place: out = (max(out, per-clip max - 8) + 4) / 4; per_clip = n_mels * n_frames (% 4 == 0). */
 int pm_logmel_finalize(float* out, const int32_t* peak, int64_t B, int64_t per_clip, void* stream);
 

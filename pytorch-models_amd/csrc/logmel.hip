@@ -29,6 +29,11 @@ __device__ __forceinline__ int enc_max(float f) {  // order-preserving float -> 
 }
 __device__ __forceinline__ float dec_max(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
+// FOLD: the window is symmetric (w[n] == w[N - n], every Hann / Hamming / ...), so w[n] cos is even and w[n] sin odd about N / 2:
+//   Re[k] = sum_{n=0}^{N/2} c[k][n] (x[n] + x[N - n]),  Im[k] = sum_{n=1}^{N/2-1} s[k][n] (x[n] - x[N - n])
+// with the n = N / 2 cosine entry halved and x[N] := 0 - half the steps of the plain form for two more LDS reads and two adds
+// per step (the tables then hold n = 0 .. N/2 (+ zero padding to an even count) instead of n = 0 .. N - 1).
+template <bool FOLD>
 __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__ x, int64_t x_stride, int T,
                                                        const float* __restrict__ tw_cos, const float* __restrict__ tw_sin,
                                                        int n_fft, int hop, int nbins, int nblk, int n_frames,
@@ -39,6 +44,8 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* smp = lds;                  // skewed samples
   float* pw = lds + nsamp_skewed;    // power tile [bin][32 frames]
+  // FOLD: skewed offsets of sample n and of its mirror N - n inside a frame, n = 0 .. 2 * steps - 1 (behind the power tile)
+  int* fpos = (int*)(lds + nsamp_skewed + (mode ? nbins * FT : 0));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / tiles_per_clip;
@@ -55,10 +62,18 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
     s = s < 0 ? 0 : (s >= T ? T - 1 : s);  // frames past the clip end (masked at the store) may reflect twice
     smp[i + i / hop] = xb[s];
   }
+  const int steps = FOLD ? ((n_fft >> 1) + 2) >> 1 : n_fft >> 1;
+  if constexpr (FOLD) {
+    for (int n = tid; n < 2 * steps; n += 256) {
+      const int nn = n <= n_fft / 2 ? n : n_fft / 2;  // zero-weighted padding entries: any valid sample
+      const int m = nn == 0 ? 0 : n_fft - nn;         // x[N] does not belong to the frame: n = 0 reads x[0] and drops the mirror
+      fpos[2 * n] = nn + nn / hop;
+      fpos[2 * n + 1] = m + m / hop;
+    }
+  }
   __syncthreads();
 
   const int j = lane & 31, kk = lane >> 5;
-  const int steps = n_fft >> 1;
   for (int blk = wave; blk < nblk; blk += 4) {
     f32x16 re, im;
 #pragma unroll
@@ -66,8 +81,20 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
     const float* pc = tw_cos + (int64_t)blk * steps * 64 + lane;
     const float* ps = tw_sin + (int64_t)blk * steps * 64 + lane;
     const float* sj = smp + (hop + 1) * j + kk;
+    if constexpr (FOLD) {
+      const float* fj = smp + (hop + 1) * j;
+#pragma unroll 4
+      for (int u = 0; u < steps; ++u) {
+        const int n = 2 * u + kk;
+        const int2 pp = *(const int2*)(fpos + 2 * n);
+        const float a = fj[pp.x];
+        const float m = n ? fj[pp.y] : 0.f;
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[u * 64], a + m, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(ps[u * 64], a - m, im, 0, 0, 0);
+      }
+    }
     // k = 2*s + kk; its skew is k / hop: walk hop-sized segments so the skew is a loop constant
-    int s = 0;
+    int s = FOLD ? steps : 0;
     for (int seg = 0; s < steps; ++seg) {
       int s_end = ((seg + 1) * hop) >> 1;  // hop is even: segment boundaries fall between steps
       if (s_end > steps) s_end = steps;
@@ -141,10 +168,9 @@ __global__ void fill_int_kernel(int* p, int v, int n) {
 
 }  // namespace
 
-extern "C" int pm_stft_mel(const float* x, int64_t x_stride, int64_t B, int64_t T, const float* tw_cos,
-                           const float* tw_sin, int64_t n_fft, int64_t hop, int64_t n_frames, int mode,
-                           const int32_t* mel_ptr, const int32_t* mel_col, const float* mel_val, int64_t n_mels,
-                           float* out, int32_t* peak, void* stream) {
+static int stft_mel_impl(const float* x, int64_t x_stride, int64_t B, int64_t T, const float* tw_cos, const float* tw_sin,
+                         int64_t n_fft, int64_t hop, int64_t n_frames, int mode, const int32_t* mel_ptr, const int32_t* mel_col,
+                         const float* mel_val, int64_t n_mels, float* out, int32_t* peak, bool fold, void* stream) {
   if (!x || !tw_cos || !tw_sin || !out || B < 0 || T <= 0 || n_frames < 0) return PM_EINVAL;
   if (mode < 0 || mode > 2) return PM_EINVAL;
   if (mode != 0 && (!mel_ptr || !mel_col || !mel_val || n_mels <= 0)) return PM_EINVAL;
@@ -155,7 +181,9 @@ extern "C" int pm_stft_mel(const float* x, int64_t x_stride, int64_t B, int64_t 
   const int nbins = (int)(n_fft / 2 + 1), nblk = (nbins + 31) / 32;
   const int nsamp = (int)(hop * (FT - 1) + n_fft);
   const int nsamp_skewed = ((nsamp + nsamp / (int)hop + 1) + 3) & ~3;
-  const size_t lds_bytes = (size_t)(nsamp_skewed + (mode ? nbins * FT : 0)) * 4;
+  const int steps_f = ((int)(n_fft / 2) + 2) / 2;
+  const int fold_ints = fold ? 4 * steps_f : 0;  // two offsets (sample, mirror) for each of the 2 * steps_f table positions
+  const size_t lds_bytes = (size_t)(nsamp_skewed + (mode ? nbins * FT : 0) + fold_ints) * 4;
   if (lds_bytes > 64 * 1024) return PM_EUNSUPPORTED;
   const int tiles_per_clip = (int)((n_frames + FT - 1) / FT);
   if (B * tiles_per_clip > 0x7fffffff) return PM_EINVAL;
@@ -163,11 +191,32 @@ extern "C" int pm_stft_mel(const float* x, int64_t x_stride, int64_t B, int64_t 
   if (mode == 2)
     hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, (int*)peak, (int)0x80000000,
                        (int)B);
-  hipLaunchKernelGGL(stft_mel_kernel, dim3((unsigned)(B * tiles_per_clip)), dim3(256), lds_bytes, st, x, x_stride, (int)T,
-                     tw_cos, tw_sin, (int)n_fft, (int)hop, nbins, nblk, (int)n_frames, tiles_per_clip, mode, mel_ptr,
-                     mel_col, mel_val, (int)n_mels, out, (int*)peak, nsamp_skewed);
+  if (fold)
+    hipLaunchKernelGGL(stft_mel_kernel<true>, dim3((unsigned)(B * tiles_per_clip)), dim3(256), lds_bytes, st, x, x_stride, (int)T,
+                       tw_cos, tw_sin, (int)n_fft, (int)hop, nbins, nblk, (int)n_frames, tiles_per_clip, mode, mel_ptr,
+                       mel_col, mel_val, (int)n_mels, out, (int*)peak, nsamp_skewed);
+  else
+    hipLaunchKernelGGL(stft_mel_kernel<false>, dim3((unsigned)(B * tiles_per_clip)), dim3(256), lds_bytes, st, x, x_stride, (int)T,
+                       tw_cos, tw_sin, (int)n_fft, (int)hop, nbins, nblk, (int)n_frames, tiles_per_clip, mode, mel_ptr,
+                       mel_col, mel_val, (int)n_mels, out, (int*)peak, nsamp_skewed);
   PM_CHECK_LAUNCH();
   return PM_OK;
+}
+
+extern "C" int pm_stft_mel(const float* x, int64_t x_stride, int64_t B, int64_t T, const float* tw_cos,
+                           const float* tw_sin, int64_t n_fft, int64_t hop, int64_t n_frames, int mode,
+                           const int32_t* mel_ptr, const int32_t* mel_col, const float* mel_val, int64_t n_mels,
+                           float* out, int32_t* peak, void* stream) {
+  return stft_mel_impl(x, x_stride, B, T, tw_cos, tw_sin, n_fft, hop, n_frames, mode, mel_ptr, mel_col, mel_val, n_mels, out, peak,
+                       false, stream);
+}
+
+extern "C" int pm_stft_mel_folded(const float* x, int64_t x_stride, int64_t B, int64_t T, const float* tw_cos,
+                                  const float* tw_sin, int64_t n_fft, int64_t hop, int64_t n_frames, int mode,
+                                  const int32_t* mel_ptr, const int32_t* mel_col, const float* mel_val, int64_t n_mels,
+                                  float* out, int32_t* peak, void* stream) {
+  return stft_mel_impl(x, x_stride, B, T, tw_cos, tw_sin, n_fft, hop, n_frames, mode, mel_ptr, mel_col, mel_val, n_mels, out, peak,
+                       true, stream);
 }
 
 extern "C" int pm_logmel_finalize(float* out, const int32_t* peak, int64_t B, int64_t per_clip, void* stream) {

@@ -29,6 +29,7 @@ SIGNATURES = {
     "pm_ln_stats_finalize": ([_p, _p, _l, _l, _f, _p], c_int),
     "pm_linear_ln_supported": ([_l, _l, _l, _i, _i], c_int),
     "pm_stft_mel": ([_p, _l, _l, _l, _p, _p, _l, _l, _l, _i, _p, _p, _p, _l, _p, _p, _p], c_int),
+    "pm_stft_mel_folded": ([_p, _l, _l, _l, _p, _p, _l, _l, _l, _i, _p, _p, _p, _l, _p, _p, _p], c_int),
     "pm_logmel_finalize": ([_p, _p, _l, _l, _p], c_int),
     "pm_whisper_stem1": ([_p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_embed_tokens": ([_p, _p, _p, _p, _i, _l, _l, _l, _l, _l, _p], c_int),

@@ -344,22 +344,39 @@ def avgpool_time2(x: Tensor) -> Tensor:
     return out
 
 
-def stft_tables(window: Tensor, n_fft: int) -> tuple[Tensor, Tensor]:
-    """Twiddle tables of pm_stft_mel (window folded in), built in float64 on the host, laid out
-    [ceil(nbins / 32)][n_fft / 2][64] (see include/pm_mi355x.h)."""
+def stft_tables(window: Tensor, n_fft: int) -> tuple[Tensor, Tensor, bool]:
+    """Twiddle tables of pm_stft_mel / pm_stft_mel_folded (window folded in), built in float64 on the host.  A symmetric window
+    (w[k] == w[n_fft - k]: torch.hann_window and friends) gets the folded layout [ceil(nbins / 32)][(n_fft / 2 + 2) / 2][64] -
+    half the contraction; anything else the plain [ceil(nbins / 32)][n_fft / 2][64] (see include/pm_mi355x.h).  The third item
+    says which."""
     nbins = n_fft // 2 + 1
     nblk = (nbins + 31) // 32
-    k = torch.arange(n_fft, dtype=torch.float64)
+    w = window.detach().double().cpu()
+    # symmetric up to the rounding of the window's own construction (torch.hann_window: 3e-7 between w[k] and w[N - k] in fp32);
+    # the folded form then uses the mean of the two - a relative change of 1.5e-7 per term, two orders below the parity tolerance
+    folded = n_fft % 2 == 0 and n_fft >= 4 and float((w[1:] - w[1:].flip(0)).abs().max()) <= 1e-6 * float(w.abs().max())
+    if folded:
+        w = w.clone()
+        w[1:] = 0.5 * (w[1:] + w[1:].flip(0))
+    nk = 2 * ((n_fft // 2 + 2) // 2) if folded else n_fft  # table positions k
+    k = torch.arange(nk, dtype=torch.float64)
     b = torch.arange(nblk * 32, dtype=torch.float64)
     ang = 2.0 * torch.pi * torch.outer(k, b) / n_fft
-    w = window.detach().double().cpu()[:, None]
+    wk = torch.zeros(nk, dtype=torch.float64)
+    if folded:
+        wk[: n_fft // 2 + 1] = w[: n_fft // 2 + 1]
+        wc, ws = wk.clone(), wk.clone()
+        wc[n_fft // 2] *= 0.5  # this term meets its own mirror: x[N/2] + x[N/2]
+        ws[0] = ws[n_fft // 2] = 0.0
+    else:
+        wc = ws = w
     valid = (b < nbins)[None, :]
     out = []
-    for tab in (torch.cos(ang), torch.sin(ang)):
-        tab = (tab * w * valid).float()  # (n_fft, nblk * 32)
-        tab = tab.view(n_fft // 2, 2, nblk, 32).permute(2, 0, 1, 3).contiguous().view(-1)
+    for tab, wt in ((torch.cos(ang), wc), (torch.sin(ang), ws)):
+        tab = (tab * wt[:, None] * valid).float()  # (nk, nblk * 32)
+        tab = tab.view(nk // 2, 2, nblk, 32).permute(2, 0, 1, 3).contiguous().view(-1)
         out.append(tab.to(window.device))
-    return out[0], out[1]
+    return out[0], out[1], folded
 
 
 def mel_csr(filters: Tensor) -> tuple[Tensor, Tensor, Tensor]:
@@ -384,7 +401,8 @@ def stft_mel(x: Tensor, tables, n_fft: int, hop: int, n_frames: int, mode: int, 
     out = torch.empty((B, rows, n_frames), dtype=torch.float32, device=x.device)
     peak = torch.empty(max(B, 1), dtype=torch.int32, device=x.device) if mode == 2 else None
     ptr, col, val = csr if csr is not None else (None, None, None)
-    rc = _launch("stft_mel", float(x2.numel() * 4 + out.numel() * 4), lambda: lib().pm_stft_mel(
+    fn = lib().pm_stft_mel_folded if len(tables) > 2 and tables[2] else lib().pm_stft_mel
+    rc = _launch("stft_mel", float(x2.numel() * 4 + out.numel() * 4), lambda: fn(
         x2.data_ptr(), T, B, T, tables[0].data_ptr(), tables[1].data_ptr(), n_fft, hop, n_frames, mode,
         ptr.data_ptr() if ptr is not None else None, col.data_ptr() if col is not None else None,
         val.data_ptr() if val is not None else None, n_mels, out.data_ptr(), peak.data_ptr() if peak is not None else None,
