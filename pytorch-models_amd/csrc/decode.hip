@@ -453,6 +453,23 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   const int tpos = SELF ? *pos_ptr : 0;
   const int Lk = SELF ? tpos + 1 : lk_const;
 
+  // ---- everything small that the chain LayerNorm -> projection needs is requested FIRST, in the order of its use: loads return
+  // in order, so whatever is issued ahead of the row (weights, the K stream) delays the LayerNorm, and a gamma / beta / bias
+  // load issued where it is used exposes one L2 latency each (measured: the block spent ~2 us of its 10-25 us waiting on them)
+  const float* xr = x + (int64_t)b * d;
+  float xe[3], ge[3], be[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int k = tid + i * DF_THREADS;
+    xe[i] = k < d ? xr[k] : 0.f;
+    ge[i] = k < d ? gamma[k] : 0.f;
+    be[i] = k < d ? beta[k] : 0.f;
+  }
+  float bpe[SELF ? 3 : 1];
+#pragma unroll
+  for (int o = 0; o < (SELF ? 3 : 1); ++o) bpe[o] = bp ? bp[o * inner + h * 64 + (tid >> 3)] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- projection weights: 8 lanes per output row, lane p owns 16-byte chunks p, p+8, ...
   const int prow = tid >> 3, pl = tid & 7;
   const int nch = d >> 6;  // chunks per lane (d % 64 == 0)
@@ -484,15 +501,9 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     kv[u] = SELF ? *(const bf16x8*)(kb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(kb + key * sk));
   }
   // ---- LayerNorm of row b (two-pass from registers)
-  const float* xr = x + (int64_t)b * d;
-  float xe[3];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int k = tid + i * DF_THREADS;
-    xe[i] = k < d ? xr[k] : 0.f;
-    s += xe[i];
-  }
+  for (int i = 0; i < 3; ++i) s += xe[i];
   const float mean = block_reduce8(s, scratch, false) / (float)d;
   float q2 = 0.f;
 #pragma unroll
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int k = tid + i * DF_THREADS;
-    if (k < d) xn[k] = (xe[i] - mean) * rstd * gamma[k] + beta[k];
+    if (k < d) xn[k] = (xe[i] - mean) * rstd * ge[i] + be[i];
   }
   __syncthreads();
   // ---- q (k, v) = W xn + b : fp32 FMA over this lane's chunks, then across the 8 lanes of the row
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
     if (pl == 0) {
-      float v = acc + (bp ? bp[o * inner + h * 64 + prow] : 0.f);
+      float v = acc + bpe[o];
       if (SELF && o > 0) {  // cached k / v are bf16: round once, store, and use the rounded value for this step too
         const bf16 r = (bf16)v;
         (o == 1 ? Kc : Vc)[b * sb + h * sh + (int64_t)tpos * sk + prow] = r;
