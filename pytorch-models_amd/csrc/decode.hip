@@ -72,6 +72,34 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   const int kparts = gridDim.y, kp = blockIdx.y;
   const int ks0 = ksteps * kp / kparts, ks1 = ksteps * (kp + 1) / kparts;
 
+  // ---- the epilogue's operands (bias, residual) are requested before anything else by the wave that will run it: issued
+  // where they are used they cost one exposed L2 round trip per launch, ~1 us of a 4-9 us kernel (the residual only while it
+  // fits a few registers: out_proj / fc2 shapes)
+  constexpr bool PRE_R = FT * MT <= 4;
+  constexpr bool PRE_B = FT * MT <= 8;  // the 4 x 4 vocabulary tiles have no registers to spare (and no bias)
+  f32x4 bpre[PRE_B ? FT : 1], rpre[PRE_R ? FT : 1][PRE_R ? MT : 1];
+  const bool pre_resid = PRE_R && resid && mode == DL_PLAIN;
+  if constexpr (PRE_B || PRE_R)
+  if (wave == 0) {
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const int n = n0 + f * 16 + kq * 4;
+      if constexpr (PRE_B) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bpre[f][r] = (bias && n + r < N) ? bias[n + r] : 0.f;
+      }
+      if constexpr (PRE_R) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int row = rbase + t * 16 + fi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rpre[f][t][r] = (pre_resid && row < M && n + r < N) ? resid[(int64_t)row * ldr + n + r] : 0.f;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
   f32x4 acc[FT][MT];
 #pragma unroll
   for (int f = 0; f < FT; ++f)
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
       for (int r = 0; r < 4; ++r) {
         const int nn = n + r;
         if (nn >= N) continue;
-        float e = v[r] + (bias ? bias[nn] : 0.f);
+        float e = v[r] + (PRE_B ? bpre[PRE_B ? f : 0][r] : (bias ? bias[nn] : 0.f));
         e = apply_act<ACT, true>(e);
         if (mode == DL_ARGMAX) {
           if (e > best_v[t]) { best_v[t] = e; best_i[t] = nn; }  // ascending nn: strict > keeps the lowest index
@@ -251,7 +279,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         }
         if (row >= M) continue;
         if (mode == DL_PLAIN) {
-          if (resid) e += resid[(int64_t)row * ldr + nn];
+          if constexpr (PRE_R) e += rpre[f][t][r];
+          else if (resid) e += resid[(int64_t)row * ldr + nn];
           out[(int64_t)row * ldo + nn] = e;
         } else {  // DL_QKV: [q | k | v] column blocks of width inner
           const int which = nn / inner, c = nn - which * inner;
