@@ -694,8 +694,17 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
   __shared__ int si[4];
   __shared__ float s2[4];
   __shared__ int64_t snext;
-  __shared__ int st;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // what does not depend on the winner is requested up front, in the order of its use (loads return in order): the position,
+  // the forced prompt token and the next step's positional row - each used to cost its own round trip after the reduction
+  const int t = *pos_ptr;  // the token just consumed sits at position t; this step decides position t + 1
+  const int t1 = t + 1;
+  const int64_t forced = t1 < P ? prompt[(int64_t)b * P + t1] : -1;
+  f32x4 pp0 = {0.f, 0.f, 0.f, 0.f}, pp1 = pp0;
+  if (E && tid < d / 8) {
+    pp0 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + tid * 8);
+    pp1 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + tid * 8 + 4);
+  }
   float bv = -INFINITY, second = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = tid; i < nwg; i += 256) {
@@ -719,26 +728,27 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
       if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { second = fmaxf(fmaxf(second, s2[w]), bv); bv = sv[w]; bi = si[w]; }
       else second = fmaxf(fmaxf(second, s2[w]), sv[w]);
     }
-    const int t = *pos_ptr;  // the token just consumed sits at position t; this step decides position t + 1
-    const int64_t next = (t + 1 < P) ? prompt[(int64_t)b * P + t + 1] : (int64_t)bi;
+    const int64_t next = (t1 < P) ? forced : (int64_t)bi;
     tok_cur[b] = next;
     if (t + 1 < Ttot) tokens_out[(int64_t)b * Ttot + t + 1] = next;
     // NOTE: `second` is the runner-up among per-tile winners, i.e. a lower bound on the true top1 - top2 margin's
     // complement; it is diagnostic only (tests classify near-ties with it).
     if (margin_out && t + 1 < Ttot) margin_out[(int64_t)b * Ttot + t + 1] = bv - second;
     snext = next;
-    st = t;
   }
   if (!E) return;
   // ---- fused tail: the next step's input row x[b] = E[next] + pos[t + 1] (what dec_embed would compute after the
   // position moved), then the LAST workgroup to get here moves the position: every workgroup read it before its ticket
   __syncthreads();
-  const int t1 = st + 1;
   int64_t id = snext;
   id = id < 0 ? 0 : (id >= V ? V - 1 : id);
   for (int c = tid; c < d / 8; c += 256) {
     const bf16x8 e = *(const bf16x8*)(E + id * d + c * 8);
-    const f32x4 p0 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8), p1 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8 + 4);
+    f32x4 p0 = pp0, p1 = pp1;
+    if (c != tid) {  // d > 2048 only
+      p0 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8);
+      p1 = *(const f32x4*)(pos_tab + (int64_t)t1 * d + c * 8 + 4);
+    }
     f32x4 o0, o1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o0[i] = (float)e[i] + p0[i]; o1[i] = (float)e[4 + i] + p1[i]; }
