@@ -61,6 +61,18 @@ __device__ __forceinline__ f32x4 load_sc1_x4(const f32x4* p) {
   return v;
 }
 
+// The same load WITHOUT its wait, and the wait that publishes up to four of them: a combine loop that waits per load pays one L2
+// round trip per partial (the K-split combine: kparts of them in series), this pays one.  The registers pass through the wait
+// as in/out operands so that nothing that consumes them can be scheduled ahead of it.
+__device__ __forceinline__ f32x4 load_sc1_x4_async(const f32x4* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one rcp, one exp, five fma.

@@ -252,9 +252,19 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
     for (int f = 0; f < FT; ++f)
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
+        // parts in groups of four: the loads of a group are in flight together, one wait, then added in part order
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < kparts; ++q) {
-          v += load_sc1_x4((const f32x4*)ws_val + ((int64_t)(tile_id * kparts + q) * FT * MT + f * MT + t) * 64 + lane);
+        for (int q0 = 0; q0 < kparts; q0 += 4) {
+          f32x4 pq[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int q = q0 + j < kparts ? q0 + j : kparts - 1;
+            pq[j] = load_sc1_x4_async((const f32x4*)ws_val + ((int64_t)(tile_id * kparts + q) * FT * MT + f * MT + t) * 64 + lane);
+          }
+          wait_loads(pq[0], pq[1], pq[2], pq[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (q0 + j < kparts) v += pq[j];
         }
         vs[f][t] = v;
       }
