@@ -42,6 +42,14 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& hi, bf16x8& 
 
 enum { DL_PLAIN = 0, DL_QKV = 1, DL_ARGMAX = 2 };
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() carries a fence that waits for EVERY outstanding
+// memory operation - also the global loads a kernel has deliberately left in flight (its weight stream) - so a reduction in the
+// middle of a kernel would drain them.  This one waits for the LDS traffic alone.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // NSTEP = K steps of 32 per wave held in registers at once.  LayerNorm kernels (K = d_model) keep the wave's WHOLE
 // share of x in registers: the row statistics come from those registers (two exchanges through LDS: mean, then the
 // centred second moment - the reference's two-pass form), so x is read from memory exactly once and every load of the
@@ -125,6 +133,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   for (int sb = ks0 + wave, trip = 0; LN ? trip < 1 : sb < ks1; sb += 4 * NSTEP, ++trip) {
     bf16x8 a[NSTEP][FT];
     f32x4 xv[NSTEP][MT][2];
+    // LayerNorm kernels: the activations first, then gamma / beta, then the weights - loads return in order and the row
+    // statistics need only x, so they run while the weights stream (with LDS-only barriers: see lds_barrier)
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u) {
       int s = sb + 4 * u;
@@ -134,12 +144,26 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         xv[u][t][0] = *(const f32x4*)(xrow[t] + s * 32);
         xv[u][t][1] = *(const f32x4*)(xrow[t] + s * 32 + 4);
       }
+      if constexpr (!LN) {
 #pragma unroll
-      for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
+        for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
+      }
+    }
+    if constexpr (LN) {
+      __builtin_amdgcn_sched_barrier(0);
+      for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NSTEP; ++u) {
+        int s = sb + 4 * u;
+        s = s < ks1 ? s : ks1 - 1;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     float mean[MT], rstd[MT];
     if constexpr (LN) {
-      for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
       // ---- mean: lane partial over its elements, then over the 4 kq lanes, then over the 4 waves through LDS
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -154,13 +178,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         sm += __shfl_xor(sm, 32, 64);
         if (kq == 0) part[wave * 64 + t * 16 + fi] = sm;
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         const int r = t * 16 + fi;
         mean[t] = ((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K;
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         float q = 0.f;
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         q += __shfl_xor(q, 32, 64);
         if (kq == 0) part[wave * 64 + t * 16 + fi] = q;
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         const int r = t * 16 + fi;
