@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   // ---- the epilogue's operands (bias, residual) are requested before anything else by the wave that will run it: issued
   // where they are used they cost one exposed L2 round trip per launch, ~1 us of a 4-9 us kernel (the residual only while it
   // fits a few registers: out_proj / fc2 shapes)
+  const int tpos = (mode == DL_QKV) ? *pos_ptr : 0;  // cache position of the k / v rows written by the epilogue
   constexpr bool PRE_R = FT * MT <= 4;
   constexpr bool PRE_B = FT * MT <= 8;  // the 4 x 4 vocabulary tiles have no registers to spare (and no bias)
   f32x4 bpre[PRE_B ? FT : 1], rpre[PRE_R ? FT : 1][PRE_R ? MT : 1];
@@ -241,7 +242,6 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   if (wave != 0) return;
 
   // D[row = feature 4*kq + r][col = sequence fi]; partial sums added in wave order 0..3
-  const int tpos = (mode == DL_QKV) ? *pos_ptr : 0;
   float best_v[MT];
   int best_i[MT];
 #pragma unroll
