@@ -1,17 +1,24 @@
 """bench.py - the hot path on N MI355X of one node, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vit|whisper]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload both|vit|whisper|stub]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one per-GPU batch of synthetic input already resident in HBM:
+BASELINE.json's metric has two halves and the default run times BOTH, each for exactly K steps after W warm-ups:
   vit     : ViT-B/16 bf16 forward, batch 256 per GPU, 224x224 (BASELINE.json configs[1])
-  whisper : Whisper-base log-mel + encoder + 224-step greedy decode, 32 x 30 s clips per GPU (configs[2])
-For N > 1 every rank runs its own shard (weak scaling, no data-path collective) and the step ends with
-the one RCCL all_gather of the outputs.  Rank 0 prints ONE JSON line.
+  whisper : Whisper-base log-mel + encoder + 224-step KV-cached greedy decode, 32 x 30 s clips per GPU (configs[2])
+One "step" = one pass of the hot path over one per-GPU batch of synthetic input already resident in HBM.
+Rank 0 prints ONE JSON line: the top-level metric fields are the ViT-B/16 leg (the configuration the metric is quoted on
+first), the Whisper leg is the "whisper" object and is repeated under config.legs / roofline.whisper / cpu_baseline.whisper.
+For N > 1 every rank runs its own shard (weak scaling, no data-path collective) and each step ends with the product's
+one gather of the outputs (pytorch_models.dp.OutputGatherer: RCCL all_gather over xGMI under backend "nccl").
+`--gpus N` without a torch.distributed environment starts the N ranks itself (child processes, before any HIP call).
+`--workload stub` is a CPU stand-in step (no HIP) that drives exactly this file's N > 1 code path under gloo.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +32,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM_GBS = 8000.0
+PROFILE_DIRS = ("r02", "r01")  # committed rocprofv3 PMC summaries, newest first
 
 
 def host_cores() -> int:
@@ -40,12 +48,13 @@ def host_cores() -> int:
 
 
 def measured_traffic(name: str):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/collect_traffic.py;
-    PMC cannot be sampled from inside this process).  None if no measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", name)
-    if not os.path.exists(path):
-        return None
-    return round(json.load(open(path))["traffic_bytes_per_launch"])
+    """(HBM-side bytes per launch of the dominant kernel, file) from the committed rocprofv3 PMC passes
+    (tools/collect_traffic.py; PMC cannot be sampled from inside this process).  (None, None) if nothing is committed."""
+    for r in PROFILE_DIRS:
+        path = os.path.join(ROOT, "profiles", r, name)
+        if os.path.exists(path):
+            return round(json.load(open(path))["traffic_bytes_per_launch"]), f"profiles/{r}/{name}"
+    return None, None
 
 
 def vit_flops_per_image(n_layers=12, d=768, L=197, patches=196, k_patch=768) -> float:
@@ -79,7 +88,20 @@ def cpu_baseline_vit(seconds_budget: float = 20.0) -> dict:
             "sample": f"{n} images (batches of 8) of ViT-B/16 224x224, fp32 oracle, torch threads={cores}"}
 
 
+def timed_steps(step, args, world):
+    """W untimed warm-ups, then EXACTLY K steps between barrier + synchronize pairs; seconds of the timed region."""
+    for _ in range(args.warmup):
+        step()
+    sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(world)
+    return time.perf_counter() - t0
+
+
 def run_vit(args, rank, world, device):
+    from pytorch_models import dp
     from pytorch_models._hip import ops
     from pytorch_models.image import ViT
     from synthweights import fill_module, synth_input
@@ -89,23 +111,14 @@ def run_vit(args, rank, world, device):
     fill_module(m, 32)
     m = m.to(torch.bfloat16).to(device)
     imgs = synth_input(f"vit_bench_r{rank}", (B, 3, 224, 224), 100 + rank).to(device)
-    gathered = [torch.empty(B, 768, dtype=torch.bfloat16, device=device) for _ in range(world)] if world > 1 else None
+    gather = dp.OutputGatherer(B * world, (768,), torch.bfloat16, device) if world > 1 else None
 
     def step():
         out = m(imgs)
-        if world > 1:
-            dist.all_gather(gathered, out)
-        return out
+        return gather(out) if gather is not None else out
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        sync(world)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync(world)
-        dt = time.perf_counter() - t0
+        dt = timed_steps(step, args, world)
         # roofline leg: the SAME K steps once more with two HIP events around every launch (recorded on the launch
         # stream).  Kept out of the timed region: the event records themselves open ~10 us gaps between kernels
         # (measured: 6 % of the step), which would tax `value` without changing the per-kernel durations.
@@ -119,12 +132,13 @@ def run_vit(args, rank, world, device):
         sync(world)
     dt = max_over_ranks(dt, world, device)
     res = {
-        "metric": "ViT-B/16 images/s (BASELINE.json: Whisper-base audio-sec/s & ViT-B/16 images/s)",
+        "metric": "ViT-B/16 images/s",
         "value": round(world * B * args.steps / dt, 1),
         "unit": "images/s",
+        "ms_per_step": round(1e3 * dt / args.steps, 3),
         "config": {"workload": f"ViT-B/16 bf16 forward, batch={B} per GPU, 224x224 (BASELINE configs[1])",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "collective": "all_gather(outputs)" if world > 1 else "none"},
+                   "collective": "dp.OutputGatherer: all_gather_into_tensor(outputs)" if world > 1 else "none"},
         "dtype": "bf16",
         "_dt": dt,
     }
@@ -132,9 +146,12 @@ def run_vit(args, rank, world, device):
         kern = summarize_launches(log)
         lin = kern["linear_bf16"]
         ach = lin["work"] / lin["ms"] / 1e9  # flop / ms -> TFLOP/s
-        res["roofline"] = {"bound": "mfma", "kernel": "linear_bf16_kernel", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                           "traffic": measured_traffic("vit_traffic.json"), "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01/vit_traffic.json)",
+        traffic, tfile = measured_traffic("vit_traffic.json")
+        res["roofline"] = {"bound": "mfma", "kernel": "linear_bf16 kernels (QKV, out_proj, fc1 + GELU, fc2 of 12 layers)",
+                           "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                           "traffic_unit": f"bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, {tfile})",
+                           "algorithmic_bytes_per_launch": round(lin["bytes"] / lin["n"]) if lin.get("bytes") else None,
                            "launches": lin["n"], "avg_launch_us": round(1e3 * lin["ms"] / lin["n"], 2)}
         res["kernels"] = {k: {"launches": v["n"], "total_ms": round(v["ms"], 3)} for k, v in kern.items()}
         res["model_tflops"] = round(vit_flops_per_image() * B * args.steps / dt / 1e12, 1)
@@ -142,18 +159,48 @@ def run_vit(args, rank, world, device):
     return res
 
 
+def run_stub(args, rank, world, device):
+    """CPU stand-in for a model step (tests/test_dp_gloo.py): per-sample arithmetic on this rank's shard, then the same
+    gather, timing, max-over-ranks and JSON assembly as the real legs."""
+    from pytorch_models import dp
+
+    B = args.batch or 6
+    x = torch.arange(B * 4, dtype=torch.float32).view(B, 4) + 1000.0 * rank
+    gather = dp.OutputGatherer(B * world, (2,), torch.float32, device) if world > 1 else None
+    last = {}
+
+    def step():
+        out = torch.stack([x.sum(1), x[:, 0] * 2], 1)
+        last["out"] = gather(out) if gather is not None else out
+
+    dt = timed_steps(step, args, world)
+    dt = max_over_ranks(dt, world, device)
+    want = torch.cat([torch.stack([(torch.arange(B * 4, dtype=torch.float32).view(B, 4) + 1000.0 * r).sum(1),
+                                   (torch.arange(B * 4, dtype=torch.float32).view(B, 4) + 1000.0 * r)[:, 0] * 2], 1)
+                      for r in range(world)])
+    return {"metric": "stub samples/s", "value": round(world * B * args.steps / dt, 1), "unit": "samples/s",
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "config": {"workload": "stub (CPU stand-in step, no HIP)", "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "collective": "dp.OutputGatherer" if world > 1 else "none"},
+            "dtype": "f32", "gather_ok": bool(torch.equal(last["out"], want)), "_dt": dt}
+
+
 def summarize_launches(log):
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     out = {}
     for name, evs in (log or {}).items():
-        out[name] = {"n": len(evs), "ms": sum(a.elapsed_time(b) for a, b, _ in evs), "work": sum(w for _, _, w in evs)}
+        out[name] = {"n": len(evs), "ms": sum(a.elapsed_time(b) for a, b, _ in evs),
+                     "work": sum((w[0] if isinstance(w, tuple) else w) for _, _, w in evs),
+                     "bytes": sum((w[1] if isinstance(w, tuple) else 0) for _, _, w in evs)}
     return out
 
 
 def sync(world):
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 def max_over_ranks(dt, world, device):
@@ -164,51 +211,100 @@ def max_over_ranks(dt, world, device):
     return float(t.item())
 
 
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 without RANK / WORLD_SIZE: start the N ranks as children of this process (nothing here has touched
+    the GPU yet) and relay rank 0's JSON line.  Never an exec: see the environment notes on exec after HIP init."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="vit", choices=["vit", "whisper"])
+    ap.add_argument("--workload", default="both", choices=["both", "vit", "whisper", "stub"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the BASELINE config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--whisper-layers", type=int, default=0,
                     help="whisper: layers per stack (0 = 8, the reference's \"base\"; 6 = OpenAI's base geometry, a labelled extra: SURVEY.md F2)")
-    ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL; "gloo" only to rehearse N > 1 on one GPU)')
+    ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL; "gloo" only to rehearse N > 1 on one GPU or on CPU)')
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-graph", action="store_true", help="whisper: eager decode launches instead of the captured HIP graph "
                     "(rocprofv3 --pmc cannot sample graph replays on this stack)")
+    ap.add_argument("--decode-path", default="auto", choices=["auto", "launches", "persistent"],
+                    help="whisper: force the per-stage launch list or the persistent layer kernel of the decode step")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or without a torch.distributed environment: bench.py then starts the ranks itself)")
+    cpu_only = args.workload == "stub"
     if args.single_device:
         local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1:  # before any HIP call
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(args.backend)
-
-    if args.workload == "vit":
-        res = run_vit(args, rank, world, device)
+    if cpu_only:
+        device = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
     else:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        if world > 1:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group(args.backend)
+
+    legs = {}
+    if args.workload == "stub":
+        legs["stub"] = run_stub(args, rank, world, device)
+    if args.workload in ("both", "vit"):
+        legs["vit"] = run_vit(args, rank, world, device)
+    if args.workload in ("both", "whisper"):
         from bench_whisper import run_whisper
 
-        res = run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, host_cores)
+        legs["whisper"] = run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, timed_steps)
 
     if rank == 0:
-        dt = res.pop("_dt")
-        res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
-        if not args.no_cpu_baseline and world == 1:  # rank 0, N = 1 only
-            if args.workload == "vit":
-                res["cpu_baseline"] = cpu_baseline_vit()
+        want_cpu = not args.no_cpu_baseline and world == 1  # rank 0, N = 1 only
+        if want_cpu and "vit" in legs:
+            legs["vit"]["cpu_baseline"] = cpu_baseline_vit()
+        if want_cpu and "whisper" in legs and legs["whisper"]["_layers"] == 8:  # the CPU leg is the BASELINE geometry's
+            from bench_whisper import cpu_baseline_whisper
+
+            legs["whisper"].update(cpu_baseline_whisper(host_cores()))
+        for leg in legs.values():
+            leg.pop("_dt", None)
+            leg.pop("_layers", None)
+        first = next(iter(legs.values()))
+        res = dict(first)
+        if "whisper" in legs and "vit" in legs:
+            w = legs["whisper"]
+            res["metric"] = ("ViT-B/16 images/s & Whisper-base audio-sec/s (BASELINE.json metric; value / unit / ms_per_step = the "
+                             "ViT-B/16 leg of configs[1], the Whisper-base leg of configs[2] is the \"whisper\" object)")
+            res["config"] = dict(first["config"], legs={k: {"workload": v["config"]["workload"], "value": v["value"], "unit": v["unit"],
+                                                             "ms_per_step": v["ms_per_step"]} for k, v in legs.items()})
+            res["roofline"] = dict(first["roofline"], whisper=w.get("roofline"))
+            if "cpu_baseline" in first:
+                res["cpu_baseline"] = dict(first["cpu_baseline"], whisper=w.get("cpu_baseline"),
+                                           whisper_full_recompute=w.get("cpu_baseline_full_recompute"))
+            res["whisper"] = w
+        res.update({"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "data": "synthetic"})
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

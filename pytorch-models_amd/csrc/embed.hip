@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   int64_t t = tok[row];
-  t = t < 0 ? 0 : (t >= V ? V - 1 : t);  // ids are validated on the host; clamp so a bad id cannot fault
+  t = t < 0 ? 0 : (t >= V ? V - 1 : t);  // ops.embed_tokens raises on ids outside [0, V); clamp so that a raw C-ABI caller's bad id cannot fault
   const int l = (int)(row % L) + pos0;
   for (int c = lane; c < d / 8; c += 64) {
     const bf16x8 e = *(const bf16x8*)(E + t * d + c * 8);

@@ -22,6 +22,34 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _current_device_index() -> int:
+    return _cur_device() if _cur_device is not None else torch.cuda.current_device()
+
+
+def check_devices(*ts) -> None:
+    """Every operand on ONE HIP device, and that device the CURRENT one: the C ABI launches on the current device's
+    stream with raw pointers, so a tensor of another GPU would be dereferenced by the wrong device (a page fault without
+    peer mapping).  Raises instead: call under ``with torch.cuda.device(x.device):`` or, as intended, run one
+    process per GPU with ``torch.cuda.set_device(LOCAL_RANK)``."""
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "pytorch_models (MI355X build) runs on HIP devices only: got a tensor on "
+                f"{t.device}. There is no CPU path; move the module and its inputs to 'cuda'.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"pytorch_models (MI355X build): operands on different devices ({dev} and {t.device})")
+    if dev is not None and dev.index != _current_device_index():
+        raise RuntimeError(
+            f"pytorch_models (MI355X build): operands live on {dev} but the current device is cuda:{_current_device_index()}; "
+            f"kernels launch on the current device's stream - run under `with torch.cuda.device({dev.index}):` "
+            "(one process per GPU with torch.cuda.set_device(LOCAL_RANK) is the intended use)")
+
+
 # Optional per-launch timing (bench.py's roofline leg): when LAUNCH_LOG is a dict, every wrapped launch is
 # bracketed by two HIP events recorded on the stream the kernel is launched on.
 LAUNCH_LOG: dict | None = None
@@ -53,12 +81,7 @@ def _need(cond: bool, msg: str) -> None:
 
 
 def _cuda(*ts: Tensor) -> None:
-    for t in ts:
-        if t is not None and not t.is_cuda:
-            raise RuntimeError(
-                "pytorch_models (MI355X build) runs on HIP devices only: got a tensor on "
-                f"{t.device}. There is no CPU path; move the module and its inputs to 'cuda'."
-            )
+    check_devices(*ts)
 
 
 def linear_ln_supported(M: int, N: int, K: int, act: str, produce: bool) -> bool:
@@ -73,6 +96,12 @@ def ln_stats_finalize(partials: Tensor, N: int, eps: float) -> Tensor:
         partials.data_ptr(), stats.data_ptr(), M, N, float(eps), _stream()))
     check(rc, "pm_ln_stats_finalize")
     return stats
+
+
+def _linear_bytes(x: Tensor, w: Tensor, out: Tensor, resid: Tensor | None) -> float:
+    """algorithmic bytes of one GEMM launch: every operand once (bias and LayerNorm-fold vectors are noise)"""
+    n = x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size()
+    return float(n + (resid.numel() * resid.element_size() if resid is not None else 0))
 
 
 def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none", resid: Tensor | None = None,
@@ -100,7 +129,7 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none
             _need(ln_stats.shape == (M, 2) and ln_stats.dtype == torch.float32 and ln_stats.is_contiguous()
                   and ln_s.dtype == torch.float32 and ln_s.numel() == N and ln_s.is_contiguous(), "linear: bad LayerNorm-fold operands")
         rows = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device) if want_row_stats else None
-        rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16_ln(
+        rc = _launch("linear_bf16", (2.0 * M * N * K, _linear_bytes(x, w, out, resid)), lambda: lib().pm_linear_bf16_ln(
             x.data_ptr(), x.stride(0), 0, 0, w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
             resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
             _dt(resid) if resid is not None else 0, 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act],
@@ -108,7 +137,7 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none
             rows.data_ptr() if rows is not None else None, _stream()))
         check(rc, f"pm_linear_bf16_ln(M={M}, N={N}, K={K})")
         return (out, rows) if want_row_stats else out
-    rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16(
+    rc = _launch("linear_bf16", (2.0 * M * N * K, _linear_bytes(x, w, out, resid)), lambda: lib().pm_linear_bf16(
         x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
         resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
         _dt(resid) if resid is not None else 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream()))
@@ -438,6 +467,13 @@ def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor | None, pos0: int = 0,
     B, L = tokens.shape
     V, d = emb.shape
     _need(emb.dtype == torch.bfloat16 and emb.is_contiguous(), "embed_tokens: emb bf16 (V, d)")
+    # nn.Embedding raises on an id outside [0, V) (whisper.py:48); the kernel clamps so that a bad id cannot fault, so
+    # the range is checked here (one min / max read-back; skipped inside a graph capture, where the caller has
+    # validated the example inputs eagerly during the warm-up pass)
+    if tokens.numel() and not torch.cuda.is_current_stream_capturing():
+        lo, hi = int(tokens.min()), int(tokens.max())
+        if lo < 0 or hi >= V:
+            raise IndexError(f"embed_tokens: token id {lo if lo < 0 else hi} outside the vocabulary [0, {V})")
     if pos is not None:
         _need(pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == d and pos.shape[0] >= pos0 + L,
               f"embed_tokens: need {pos0 + L} position rows, have {pos.shape[0]}")

@@ -63,17 +63,22 @@ class GreedyDecoder:
         if B > 64:
             raise NotImplementedError("greedy decode: at most 64 sequences per call (shard larger batches)")
         dev = E.device
+        ops.check_devices(E, memory, prompt if prompt.is_cuda else None)
         H = dec.layers[0].sa.n_heads
         inner = H * 64
-        if dec.layers[0].sa.head_dim != 64 or inner != d:
-            raise NotImplementedError("greedy decode: head_dim 64 with n_heads * 64 == d_model only")
+        for i, layer in enumerate(dec.layers):  # the launch list below is built per layer from ONE geometry
+            for name, att in (("sa", layer.sa), ("ca", layer.ca)):
+                if att is not None and (att.head_dim != 64 or att.n_heads != H or att.n_heads * 64 != d):
+                    raise NotImplementedError(f"greedy decode: layer {i} {name}: head_dim 64 with n_heads * 64 == d_model in every "
+                                              f"layer only (got {att.n_heads} x {att.head_dim}, d_model {d})")
+        hid_max = max(layer.mlp.linear1.out_features for layer in dec.layers)
         self.B, self.P, self.n_steps = B, P, self.Ttot - 1
         Tmax = self.Ttot
         f32 = dict(dtype=torch.float32, device=dev)
         self.x = torch.empty(B, d, **f32)
         self.q = torch.empty(B, inner, **f32)
         self.att = torch.empty(B, inner, **f32)
-        self.h = torch.empty(B, 4 * d, **f32)
+        self.h = torch.empty(B, hid_max, **f32)  # widest MLP of the stack (mlp_ratio is free: transformer.py:77)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.prompt = prompt.contiguous().to(dev)
         self.tok_cur = self.prompt[:, 0].clone()
@@ -183,6 +188,8 @@ class GreedyDecoder:
                 raise NotImplementedError("greedy decode: GELU / tanh-GELU MLPs only")
             act_code = ops.ACT[mlp.act_name]
             hid = mlp.linear1.out_features
+            if hid % 32 or mlp.linear2.in_features != hid or self.h[:, :hid].shape[1] != hid:
+                raise NotImplementedError(f"greedy decode: MLP hidden width {hid} must be a multiple of 32 and fit the scratch row")
             dec_linear(self.x, d, g, b, layer.mlp_norm.eps, mlp.linear1.weight, _f32(mlp.linear1, "b", mlp.linear1.bias), None,
                        self.h[:, :hid], hid, act=act_code)
             dec_linear(self.h[:, :hid], hid, None, None, 0.0, mlp.linear2.weight, _f32(mlp.linear2, "b", mlp.linear2.bias),

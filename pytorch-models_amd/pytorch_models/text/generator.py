@@ -21,10 +21,14 @@ class DecoderGenerator:
                      generator: torch.Generator | None = None, seed: int = 0) -> list[int]:
         """Token-level form of generate(): prompt ids -> prompt + new ids, stopping after eos_token_id (kept, as the
         reference keeps it) or max_tokens new tokens."""
-        device = next(self.model.parameters()).device
+        p0 = next(self.model.parameters())
+        device = p0.device
         tokens = list(tokens)
         n = len(tokens)
-        if topk <= 64 and hasattr(self.model, "generate") and all(l.pre_norm for l in self.model.layers):
+        # the KV-cached step kernels stream bf16 weights: a model left in fp32 (the reference's default) takes the
+        # reference's own loop below - forward() on the whole prefix per token - instead of raising in the cached path
+        kv_ok = p0.dtype == torch.bfloat16 and all(l.pre_norm for l in self.model.layers)
+        if topk <= 64 and hasattr(self.model, "generate") and kv_ok:
             room = self.model.pos_embs.shape[0] - n
             out = self.model.generate(torch.tensor([tokens], device=device), min(max_tokens, room), topk=topk, seed=seed)[0].tolist()
             new = out[n:]

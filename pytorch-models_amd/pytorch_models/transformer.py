@@ -206,7 +206,9 @@ class MHA(nn.Module):
                 ab = ab.expand(*lead, *ab.shape[-3:]).reshape(-1, *ab.shape[-3:])
             Lk_ = kh.shape[1]
             bias4 = ab.expand(ab.shape[0], ab.shape[1], Lq, Lk_)
-            if bias4.stride(3) != 1:
+            # the kernels walk the bias by (batch, head, query) strides with unit key stride; batch / head strides may be 0
+            # (broadcast), a query stride of 0 - a key-padding mask (B, 1, 1, Lk) - is materialised (Lq rows per mask)
+            if bias4.stride(3) != 1 or (Lq > 1 and bias4.stride(2) == 0):
                 bias4 = bias4.contiguous()
         o = ops.attention(qh, kh, vh, H, causal, bias4)
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])

@@ -93,6 +93,12 @@ def g_mha():
     out["h4_qk"] = m(q, k)
     out["h4_qkv"] = m(q, k, v)
     out["h4_bias"] = m(q, k, v, attn_bias=bias)
+    # key-padding masks broadcast over heads AND queries: boolean keep-mask and its additive form
+    keep = torch.ones(2, 1, 1, 9, dtype=torch.bool)
+    keep[0, ..., 6:] = False
+    keep[1, ..., 8:] = False
+    out["h4_keypad_bool"] = m(q, k, v, attn_bias=keep)
+    out["h4_keypad_add"] = m(q, k, v, attn_bias=torch.zeros(2, 1, 1, 9).masked_fill(~keep, float("-inf")))
     out["h4_causal"] = m(q, causal=True)
     out["h4_causal_rect"] = m(q, k, causal=True)  # top-left aligned, L_q != S_k
     out["h4_unbatched"] = m(q[0])  # (L, d) leading-dim-free input (tests/text/test_t5.py:27-29)

@@ -146,6 +146,11 @@ def test_mha_attn_bias_forms():
     keep[..., 0] = True  # no fully masked row
     assert rel(m(bfc(q), bfc(k), attn_bias=keep.cuda()), RT.mha(sd, "", 2, r(q), r(k), attn_bias=keep)) < 2e-2
     # the reference's own golden for attn_bias uses 4 heads of 16 (not covered); 1-head d = 64 variant of it:
+    # key-padding mask on the MFMA (head_dim 64) kernel: (B, 1, 1, Lk) bool
+    pad = torch.ones(B, 1, 1, Lk, dtype=torch.bool)
+    pad[0, ..., 100:] = False
+    pad[1, ..., 17:] = False
+    assert rel(m(bfc(q), bfc(k), attn_bias=pad.cuda()), RT.mha(sd, "", 2, r(q), r(k), attn_bias=pad)) < 2e-2
     m1, sd1 = prep(MHA(64), 27)
     q1, k1 = synth_input("mha_q", (2, 6, 64), 2), synth_input("mha_k", (2, 9, 64), 2)
     b1 = synth_input("mha_bias", (2, 1, 6, 9), 2)
@@ -171,6 +176,13 @@ def test_mha_other_head_dims_match_the_reference_goldens(golden):
     assert rel(m(bfc(q), causal=True), g["h4_causal"]) < 3e-2
     assert rel(m(bfc(q), bfc(k), causal=True), g["h4_causal_rect"]) < 3e-2
     assert rel(m(bfc(q[0])), g["h4_unbatched"]) < 3e-2
+    # key-padding mask (B, 1, 1, Lk): stride 0 over heads AND queries after expand, bool and additive
+    keep = torch.ones(2, 1, 1, 9, dtype=torch.bool)
+    keep[0, ..., 6:] = False
+    keep[1, ..., 8:] = False
+    assert rel(m(bfc(q), bfc(k), bfc(v), attn_bias=keep.cuda()), g["h4_keypad_bool"]) < 3e-2
+    add = torch.zeros(2, 1, 1, 9).masked_fill(~keep, float("-inf"))
+    assert rel(m(bfc(q), bfc(k), bfc(v), attn_bias=add.cuda()), g["h4_keypad_add"]) < 3e-2
     m, _ = prep(MHA(d, n_heads=2, head_dim=16), 23)
     assert rel(m(bfc(q)), g["h2hd16_q"]) < 3e-2
     m, _ = prep(MHA(d, head_dim=32, bias=False), 24)

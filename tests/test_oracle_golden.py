@@ -78,6 +78,13 @@ def test_mha_variants(golden):
     torch.testing.assert_close(RT.mha(sd, "", 4, q, k), g["h4_qk"], **TOL)
     torch.testing.assert_close(RT.mha(sd, "", 4, q, k, v), g["h4_qkv"], **TOL)
     torch.testing.assert_close(RT.mha(sd, "", 4, q, k, v, attn_bias=bias), g["h4_bias"], **TOL)
+    keep = torch.ones(2, 1, 1, 9, dtype=torch.bool)  # key-padding mask, broadcast over heads and queries
+    keep[0, ..., 6:] = False
+    keep[1, ..., 8:] = False
+    torch.testing.assert_close(RT.mha(sd, "", 4, q, k, v, attn_bias=keep), g["h4_keypad_bool"], **TOL)
+    add = torch.zeros(2, 1, 1, 9).masked_fill(~keep, float("-inf"))
+    torch.testing.assert_close(RT.mha(sd, "", 4, q, k, v, attn_bias=add), g["h4_keypad_add"], **TOL)
+    torch.testing.assert_close(g["h4_keypad_add"], g["h4_keypad_bool"], **TOL)
     torch.testing.assert_close(RT.mha(sd, "", 4, q, causal=True), g["h4_causal"], **TOL)
     torch.testing.assert_close(RT.mha(sd, "", 4, q, k, causal=True), g["h4_causal_rect"], **TOL)
     torch.testing.assert_close(RT.mha(sd, "", 4, q[0]), g["h4_unbatched"], **TOL)
