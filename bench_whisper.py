@@ -3,21 +3,36 @@ import os
 import time
 
 import torch
-import torch.distributed as dist
 
 PEAK_HBM_GBS = 8000.0
 N_NEW, PROMPT = 224, 4  # fixed prompt of 4 ids, max_seq_len // 2 new tokens
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def _traffic():
+def _traffic(name):
     import json
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "whisper_traffic.json")
-    return round(json.load(open(path))["traffic_bytes_per_launch"]) if os.path.exists(path) else None
+    for r in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", r, name)
+        if os.path.exists(path):
+            return round(json.load(open(path))["traffic_bytes_per_launch"]), f"profiles/{r}/{name}"
+    return None, None
+
+
+def decode_step_bytes(B, d, n_layers, V, S, P, n_new, hid=None) -> float:
+    """SURVEY.md 8(d), averaged over the steps of one run: every weight once (bf16), the packed cross K/V of every layer and
+    sequence once, the self K/V written so far (position t reads t + 1 keys)."""
+    hid = hid or 4 * d
+    weights = 2 * ((8 * d * d + 2 * d * hid) * n_layers + V * d)
+    cross = 2 * S * d * 2 * n_layers * B
+    steps = P + n_new - 1
+    self_kv = sum(2 * (t + 1) * d * 2 * n_layers * B for t in range(steps)) / steps
+    return float(weights + cross + self_kv)
 
 
 def cpu_baseline_whisper(cores: int) -> dict:
-    """Oracle (kind "port") on the host: same pipeline, 2 clips, full 224-token KV-cached greedy decode."""
+    """Oracle (kind "port") on the host, 2 clips of the same pipeline, both decode semantics:
+    KV-cached (what the HIP path computes) and full-prefix recompute per token (what the reference's generators do)."""
     from oracle import ref_spectrogram as RS
     from oracle import ref_whisper as RW
     from pytorch_models.audio2text import Whisper
@@ -33,14 +48,26 @@ def cpu_baseline_whisper(cores: int) -> dict:
         t0 = time.perf_counter()
         mel = RS.whisper_log_mel(wave, 80, "rfft")
         mem = RW.encoder(sd, "encoder.", mel)
-        RW.greedy_cached(sd, "decoder.", prompt, mem, N_NEW)
-        dt = time.perf_counter() - t0
-    return {"value": round(2 * 30 / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"2 x 30 s clips: log-mel + 8-layer encoder + {N_NEW}-token KV-cached greedy decode, fp32 oracle, "
-                      f"torch threads={cores} ({dt:.1f} s)"}
+        t_front = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ids_c, _ = RW.greedy_cached(sd, "decoder.", prompt, mem, N_NEW)
+        t_cached = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ids_r, _ = RW.greedy_recompute(sd, "decoder.", prompt, mem, N_NEW)
+        t_rec = time.perf_counter() - t0
+    same = bool(torch.equal(ids_c, ids_r))
+    what = f"2 x 30 s clips: log-mel + 8-layer encoder ({t_front:.1f} s) + {N_NEW}-token greedy decode, fp32 oracle, torch threads={cores}"
+    return {
+        "cpu_baseline": {"value": round(60.0 / (t_front + t_cached), 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+                         "sample": f"{what}; KV-cached decode ({t_cached:.1f} s)"},
+        "cpu_baseline_full_recompute": {"value": round(60.0 / (t_front + t_rec), 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+                                        "sample": f"{what}; full-prefix recompute per token, the reference's generator semantics "
+                                                  f"({t_rec:.1f} s); ids equal to the cached loop's: {same}"},
+    }
 
 
-def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, host_cores):
+def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, timed_steps):
+    from pytorch_models import dp
     from pytorch_models._hip import ops
     from pytorch_models.audio2text import Whisper, WhisperPreprocessor
     from pytorch_models.audio2text.generate import GreedyDecoder
@@ -58,11 +85,12 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
     pre = WhisperPreprocessor(tag).to(device)
     wave = synth_input(f"w_bench_r{rank}", (B, 480000), 200 + rank, scale=0.1).to(device)
     prompt = synth_tokens(f"w_bench_p{rank}", (B, PROMPT), 51865, 200 + rank).to(device)
-    gathered = [torch.empty(B, PROMPT + N_NEW, dtype=torch.int64, device=device) for _ in range(world)] if world > 1 else None
+    gather = dp.OutputGatherer(B * world, (PROMPT + N_NEW,), torch.int64, device) if world > 1 else None
+    path = getattr(args, "decode_path", "auto")
 
     with torch.no_grad():
         memory = m.encoder(pre(wave))
-        dec = GreedyDecoder(m.decoder, memory, prompt, N_NEW)
+        dec = GreedyDecoder(m.decoder, memory, prompt, N_NEW, **({} if path == "auto" else {"path": path}))
         use_graph = not getattr(args, "no_graph", False)
         dec.run(graph=use_graph)  # builds + captures the step graph once
 
@@ -70,68 +98,82 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
             mem = m.encoder(pre(wave))
             dec.rebind(mem, prompt)
             toks = dec.run(graph=use_graph)
-            if world > 1:
-                dist.all_gather(gathered, toks)
-            return toks
+            return gather(toks) if gather is not None else toks
 
-        for _ in range(args.warmup):
-            step()
-        sync(world)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync(world)
-        dt = time.perf_counter() - t0
+        dt = timed_steps(step, args, world)
         log = None
-        if rank == 0:  # per-kernel event timing of the eager (front end + encoder) launches, outside the timed region
+        t_decode = None
+        if rank == 0:  # outside the timed region: per-kernel event timing of the eager (front end + encoder) launches ...
             ops.LAUNCH_LOG = {}
             for _ in range(args.steps):
                 dec.rebind(m.encoder(pre(wave)), prompt)
             torch.cuda.synchronize()
             log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+            # ... and the decode loop alone (the same graph replays as in the timed region) between two events
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(1, min(args.steps, 5))
+            dec.run(graph=use_graph)
+            e0.record()
+            for _ in range(reps):
+                dec.run(graph=use_graph)
+            e1.record()
+            torch.cuda.synchronize()
+            t_decode = e0.elapsed_time(e1) / reps  # ms per 227-step decode
         sync(world)
     dt = max_over_ranks(dt, world, device)
     res = {
-        "metric": "Whisper-base audio-sec/s (BASELINE.json: Whisper-base audio-sec/s & ViT-B/16 images/s)",
+        "metric": "Whisper-base audio-sec/s",
         "value": round(world * B * 30.0 * args.steps / dt, 1),
         "unit": "audio-s/s",
+        "ms_per_step": round(1e3 * dt / args.steps, 3),
         "config": {"workload": f"Whisper-base ({'reference geometry: 8' if n_layers == 8 else 'EXTRA, not the BASELINE config: ' + str(n_layers)} layers, d=512): log-mel + encoder + greedy decode "
                                f"(prompt {PROMPT}, {N_NEW} new tokens, KV cache), 30 s synthetic audio, batch={B} per GPU "
                                "(BASELINE configs[2])",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "collective": "all_gather(token ids)" if world > 1 else "none"},
+                   "decode_path": getattr(dec, "path", "launches"),
+                   "collective": "dp.OutputGatherer: all_gather_into_tensor(token ids)" if world > 1 else "none"},
         "dtype": "bf16 weights and encoder activations, f32 decoder activations",
         "_dt": dt,
+        "_layers": n_layers,
     }
     if rank == 0:
         kern = summarize_launches(log)
         res["kernels"] = {k: {"launches": v["n"], "total_ms": round(v["ms"], 3)} for k, v in kern.items()}
-        # decode-step kernels run inside a graph during the timed region; time them in one extra EAGER pass with HIP
-        # events on the launch stream (same buffers, same data) for the roofline of the dominant decode kernel
+        S, d = memory.shape[1], memory.shape[2]
+        V = m.decoder.token_embs.weight.shape[0]
+        step_bytes = decode_step_bytes(B, d, n_layers, V, S, PROMPT, N_NEW)
+        us_step = 1e3 * t_decode / dec.n_steps
+        ach = step_bytes / us_step / 1e3  # bytes / us -> GB/s
+        traffic, tfile = _traffic("whisper_step_traffic.json")
+        res["roofline"] = {
+            "bound": "hbm", "kernel": f"whole decode step ({getattr(dec, 'path', 'launches')}: {len(dec.launches)} launches per step, one graph replay)",
+            "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+            "traffic": traffic, "traffic_unit": f"bytes per decode step (FETCH_SIZE x2 + WRITE_SIZE over one eager step, rocprofv3 PMC, {tfile})",
+            "algorithmic_bytes_per_step": round(step_bytes), "us_per_step": round(us_step, 2), "steps_per_decode": dec.n_steps,
+            "decode_ms": round(t_decode, 3),
+            "note": "HIP events around the graph replays of one whole decode (after the timed region); bytes = SURVEY.md 8(d) averaged over the run's positions"}
+        # per-kernel view of one eager pass (HIP events on the launch stream): the dominant kernel of the step
         with torch.no_grad():
             dec.reset()
             dlog = {}
             for i in range(dec.n_steps):
                 dec.step(dlog if i % 8 == 0 else None)  # sample every 8th step: keeps the event count bounded
             torch.cuda.synchronize()
-        S, d = memory.shape[1], memory.shape[2]
+        per = {}
+        for k, v in dlog.items():
+            n_per_step = sum(1 for f, _ in dec.launches if f.__name__ == k)
+            per[k] = {"launches_per_step": n_per_step,
+                      "us_per_step": round(1e3 * sum(a.elapsed_time(b) for a, b, _ in v) / (len(v) / n_per_step), 2)}
+        res["decode_kernels_eager"] = per
         att = dlog.get("pm_dec_attention_fused", [])
         cross = [(a, b) for a, b, ar in att if ar[18] == 0]  # self_attn == 0 <=> cross-attention block
-        if not cross:  # unfused launch list (experiments): the plain attention launches over the memory keys
-            cross = [(a, b) for a, b, ar in dlog.get("pm_dec_attention", []) if ar[6] is None]
-        cross_ms = sum(a.elapsed_time(b) for a, b in cross)
-        # algorithmic bytes per launch: packed cross K/V (bf16) + x, out (f32) + the q projection weight once
-        cross_bytes = len(cross) * (2 * B * S * d * 2 + 2 * B * d * 4 + d * d * 2)
-        ach = cross_bytes / cross_ms / 1e6
-        res["roofline"] = {"bound": "hbm", "kernel": "dec_attn_fused_kernel<false> (LN + q-proj + cross-attention over 1500 keys)", "achieved": round(ach, 1),
-                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": _traffic(),
-                           "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC on the kernel alone, profiles/r01/whisper_traffic.json)",
-                           "algorithmic_bytes_per_launch": cross_bytes // max(len(cross), 1),
-                           "launches": len(cross), "avg_launch_us": round(1e3 * cross_ms / len(cross), 2),
-                           "note": "timed in an extra eager pass after the timed region (the timed region replays a graph)"}
-        res["decode_kernels_eager_ms_per_step"] = {
-            k: round(sum(a.elapsed_time(b) for a, b, _ in v) / (len(v) / sum(1 for f, _ in dec.launches if f.__name__ == k)), 4)
-            for k, v in dlog.items()}
-        if world == 1 and not args.no_cpu_baseline and n_layers == 8:  # the CPU leg is the BASELINE geometry's
-            res["cpu_baseline"] = cpu_baseline_whisper(host_cores())
+        if cross:
+            cross_ms = sum(a.elapsed_time(b) for a, b in cross)
+            cross_bytes = 2 * B * S * d * 2 + 2 * B * d * 4 + d * d * 2  # packed cross K/V (bf16) + x, out (f32) + the q weight once
+            c_ach = len(cross) * cross_bytes / cross_ms / 1e6
+            ctraffic, cfile = _traffic("whisper_traffic.json")
+            res["roofline"]["dominant_kernel"] = {
+                "kernel": "dec_attn_fused_kernel<false> (LN + q-proj + cross-attention over 1500 keys)", "achieved": round(c_ach, 1),
+                "unit": "GB/s", "frac": round(c_ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": cross_bytes,
+                "traffic": ctraffic, "traffic_file": cfile, "avg_launch_us": round(1e3 * cross_ms / len(cross), 2), "launches": len(cross)}
     return res

@@ -41,7 +41,10 @@ class GreedyDecoder:
     """State + launch list of the decode step for one (decoder, batch, memory length) geometry."""
 
     def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False, fused: bool = True,
-                 topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None) -> None:
+                 topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None, path: str = "auto") -> None:
+        if path not in ("auto", "launches", "persistent"):
+            raise ValueError("greedy decode: path must be 'auto', 'launches' or 'persistent'")
+        self.path = "launches"
         E = dec.token_embs.weight
         if E.dtype != torch.bfloat16 or not E.is_cuda:
             raise NotImplementedError("greedy decode: bf16 weights on a HIP device only (model.to(torch.bfloat16).cuda())")
