@@ -43,6 +43,8 @@ SIGNATURES = {
     "pm_dec_advance": ([_p, _p], c_int),
     "pm_dec_whisper_rules": ([_p, _l, _l, _p, _l, _p, _l, _l, _l, _l, _l, _p, _l, _p, _l, _l, _p], c_int),
     "pm_dec_sample_topk": ([_p, _l, _l, _l, ctypes.c_uint64, _p, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p], c_int),
+    "pm_dec_layers": ([_p, _l, _l, _l, _l, _l, _l, _l, _i, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p], c_int),
+    "pm_dec_layers_grid": ([], c_int),
     "pm_dec_next_token": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _l, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
     "pm_layernorm_ex": ([_p, _l, _i, _p, _p, _f, _i, _p, _l, _i, _p, _l, _i, _l, _l, _p], c_int),
@@ -60,6 +62,15 @@ SIGNATURES = {
     "pm_vit_tokens": ([_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_vit_tokens_generic": ([_p, _p, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
 }
+
+
+
+class DecLayer(ctypes.Structure):
+    """pm_dec_layer_t of include/pm_mi355x.h (field order is the ABI)."""
+    _fields_ = [(n, c_void_p) for n in (
+        "sa_g", "sa_b", "w_qkv", "b_qkv", "kc", "vc", "w_so", "b_so", "ca_g", "ca_b", "w_q", "b_q", "cross_kv", "w_co", "b_co",
+        "mlp_g", "mlp_b", "w1", "b1", "w2", "b2")] + [(n, c_float) for n in ("sa_eps", "ca_eps", "mlp_eps", "reserved_")]
+
 
 _lib = None
 

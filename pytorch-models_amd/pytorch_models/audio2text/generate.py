@@ -16,8 +16,11 @@ from dataclasses import dataclass
 import torch
 from torch import Tensor
 
-from .._hip import check, lib, ops
+from .._hip import DecLayer, check, lib, ops
 from ..transformer import _f32
+
+
+PERSISTENT_BY_DEFAULT = True  # path="auto": the persistent layer kernel wherever it applies
 
 
 def _ptr(t: Tensor | None):
@@ -44,7 +47,6 @@ class GreedyDecoder:
                  topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None, path: str = "auto") -> None:
         if path not in ("auto", "launches", "persistent"):
             raise ValueError("greedy decode: path must be 'auto', 'launches' or 'persistent'")
-        self.path = "launches"
         E = dec.token_embs.weight
         if E.dtype != torch.bfloat16 or not E.is_cuda:
             raise NotImplementedError("greedy decode: bf16 weights on a HIP device only (model.to(torch.bfloat16).cuda())")
@@ -75,6 +77,25 @@ class GreedyDecoder:
                     raise NotImplementedError(f"greedy decode: layer {i} {name}: head_dim 64 with n_heads * 64 == d_model in every "
                                               f"layer only (got {att.n_heads} x {att.head_dim}, d_model {d})")
         hid_max = max(layer.mlp.linear1.out_features for layer in dec.layers)
+        # One persistent launch for all layers of a step (csrc/decode_persist.hip) where its geometry rules hold; the
+        # launch-per-stage list otherwise (and on request: tests compare the two)
+        L = lib()
+        nstep = 4 if d <= 512 else 8 if d <= 1024 else 10
+        ksp_p = -(-(hid_max // 32) // (4 * nstep))
+        acts = {layer.mlp.act_name for layer in dec.layers}
+        hids = {layer.mlp.linear1.out_features for layer in dec.layers}
+        persist_ok = (all(layer.pre_norm for layer in dec.layers) and len(acts) == 1 and len(hids) == 1 and d % 64 == 0 and d <= 1280
+                      and hid_max % 32 == 0 and ksp_p <= 8 and S <= 2048 and self.Ttot <= 2048 and fused
+                      and len({layer.ca is None for layer in dec.layers}) == 1 and L.pm_dec_layers_grid() > 0)
+        if path == "persistent" and not persist_ok:
+            raise NotImplementedError("greedy decode: the persistent layer kernel needs pre-norm layers of one MLP width and activation, "
+                                      "d_model % 64 == 0 <= 1280, memory and total length <= 2048")
+        env_path = os.environ.get("PM_DEC_PATH")
+        if path == "auto" and env_path in ("launches", "persistent"):
+            path = env_path if (env_path == "launches" or persist_ok) else "launches"
+        self.path = "persistent" if (path == "persistent" or (path == "auto" and persist_ok and PERSISTENT_BY_DEFAULT)) else "launches"
+        persistent = self.path == "persistent"
+        table = []
         self.B, self.P, self.n_steps = B, P, self.Ttot - 1
         Tmax = self.Ttot
         f32 = dict(dtype=torch.float32, device=dev)
@@ -88,7 +109,6 @@ class GreedyDecoder:
         self.tokens = torch.zeros(B, self.Ttot, dtype=torch.int64, device=dev)
         self.tokens[:, :P] = self.prompt
         self.margins = torch.zeros(B, self.Ttot, **f32) if margins else None
-        L = lib()
         # d_model > 512: the final LayerNorm runs once as its own launch and the vocabulary projection without the
         # in-kernel LayerNorm, whose register budget would halve the feature tile (GPT-2 small: 101 -> ~55 us per step)
         self.split_final_norm = (d // 32 + 3) // 4 > 4
@@ -156,7 +176,13 @@ class GreedyDecoder:
             env_fs = os.environ.get("PM_DEC_FUSE_SELF")
             fuse_self = fused and (B * H <= 256 if env_fs is None else env_fs != "0")
             fuse_cross = fused and os.environ.get("PM_DEC_FUSE_CROSS", "1") != "0"
-            if fuse_self:  # LN + q/k/v projection + cache append + attention in one launch per layer
+            if persistent:
+                bo = _f32(sa.out_proj, "b", sa.out_proj.bias)
+                self._keep += [sa.out_proj.weight, bo]
+                ent = DecLayer(sa_g=g.data_ptr(), sa_b=b.data_ptr(), w_qkv=wqkv.data_ptr(), b_qkv=_ptr(bqkv), kc=kc.data_ptr(),
+                               vc=vc.data_ptr(), w_so=sa.out_proj.weight.data_ptr(), b_so=_ptr(bo), sa_eps=float(layer.sa_norm.eps))
+                table.append(ent)
+            elif fuse_self:  # LN + q/k/v projection + cache append + attention in one launch per layer
                 add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
                     wqkv.data_ptr(), _ptr(bqkv), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64, self.pos.data_ptr(),
                     0, Tmax, self.att.data_ptr(), B, H, 1, None)
@@ -164,8 +190,9 @@ class GreedyDecoder:
                 dec_linear(self.x, d, g, b, layer.sa_norm.eps, wqkv, bqkv, None, self.q, 3 * inner, mode=1, kc=kc, vc=vc)
                 add(L.pm_dec_attention, self.q.data_ptr(), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64,
                     self.pos.data_ptr(), 1, Tmax, self.att.data_ptr(), B, H, None)
-            dec_linear(self.att, inner, None, None, 0.0, sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), self.x,
-                       self.x, d)
+            if not persistent:
+                dec_linear(self.att, inner, None, None, 0.0, sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), self.x,
+                           self.x, d)
             if ca is not None:
                 # cross attention: K/V of the memory projected ONCE (the reference re-projects them on every call,
                 # transformer.py:44-49), kept packed (B, S, [k | v]) in bf16
@@ -176,7 +203,13 @@ class GreedyDecoder:
                 g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
                 bq = _f32(ca.q_proj, "b", ca.q_proj.bias)
                 self._keep += [g, b, bq]
-                if fuse_cross:
+                if persistent:
+                    bo = _f32(ca.out_proj, "b", ca.out_proj.bias)
+                    self._keep += [ca.q_proj.weight, ca.out_proj.weight, bo]
+                    ent.ca_g, ent.ca_b, ent.ca_eps = g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps)
+                    ent.w_q, ent.b_q, ent.cross_kv = ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr()
+                    ent.w_co, ent.b_co = ca.out_proj.weight.data_ptr(), _ptr(bo)
+                elif fuse_cross:
                     add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
                         ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
                         2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
@@ -184,8 +217,9 @@ class GreedyDecoder:
                     dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, bq, None, self.q, inner)
                     add(L.pm_dec_attention, self.q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
                         2 * inner, None, S, S, self.att.data_ptr(), B, H, None)
-                dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), self.x,
-                           self.x, d)
+                if not persistent:
+                    dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), self.x,
+                               self.x, d)
             g, b = _f32(layer.mlp_norm, "g", layer.mlp_norm.weight), _f32(layer.mlp_norm, "b", layer.mlp_norm.bias)
             if mlp.act_name not in ("gelu", "approximate_gelu"):
                 raise NotImplementedError("greedy decode: GELU / tanh-GELU MLPs only")
@@ -193,10 +227,31 @@ class GreedyDecoder:
             hid = mlp.linear1.out_features
             if hid % 32 or mlp.linear2.in_features != hid or self.h[:, :hid].shape[1] != hid:
                 raise NotImplementedError(f"greedy decode: MLP hidden width {hid} must be a multiple of 32 and fit the scratch row")
+            if persistent:
+                b1, b2 = _f32(mlp.linear1, "b", mlp.linear1.bias), _f32(mlp.linear2, "b", mlp.linear2.bias)
+                self._keep += [g, b, mlp.linear1.weight, mlp.linear2.weight, b1, b2]
+                ent.mlp_g, ent.mlp_b, ent.mlp_eps = g.data_ptr(), b.data_ptr(), float(layer.mlp_norm.eps)
+                ent.w1, ent.b1, ent.w2, ent.b2 = mlp.linear1.weight.data_ptr(), _ptr(b1), mlp.linear2.weight.data_ptr(), _ptr(b2)
+                continue
             dec_linear(self.x, d, g, b, layer.mlp_norm.eps, mlp.linear1.weight, _f32(mlp.linear1, "b", mlp.linear1.bias), None,
                        self.h[:, :hid], hid, act=act_code)
             dec_linear(self.h[:, :hid], hid, None, None, 0.0, mlp.linear2.weight, _f32(mlp.linear2, "b", mlp.linear2.bias),
                        self.x, self.x, d)
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+        if persistent:
+            import ctypes
+
+            arr = (DecLayer * len(table))(*table)
+            self.table = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8).to(dev)
+            mt = (B + 15) // 16
+            self.ps_cnt = torch.zeros(len(table) * 24, dtype=torch.int32, device=dev)
+            ws = torch.empty((d // 16) * mt * ksp_p * 256, **f32)
+            tick = torch.zeros((d // 16) * mt, dtype=torch.int32, device=dev)
+            self._ks_bufs += [ws, tick]
+            self._ks_cnts.append(tick)
+            add(L.pm_dec_layers, self.table.data_ptr(), len(table), B, d, H, S, Tmax, hid_max, ops.ACT[acts.pop()], ksp_p,
+                self.pos.data_ptr(), self.x.data_ptr(), self.att.data_ptr(), self.h.data_ptr(), self.h.stride(0),
+                self.ps_cnt.data_ptr(), ws.data_ptr(), tick.data_ptr(), self.err.data_ptr(), None)
         g, b = _f32(dec.norm, "g", dec.norm.weight), _f32(dec.norm, "b", dec.norm.bias)
         if not 1 <= topk <= 64:
             raise ValueError("greedy decode: topk must be in 1..64")
@@ -263,6 +318,9 @@ class GreedyDecoder:
     def reset(self) -> None:
         self.pos.zero_()
         self.ticket.zero_()
+        self.err.zero_()
+        if self.path == "persistent":
+            self.ps_cnt.zero_()  # arrival counters count up by epochs of the position: zero with it
         for cnt in self._ks_cnts:  # the K-split tickets return to zero by themselves; this covers an aborted run
             cnt.zero_()
         self.tok_cur.copy_(self.prompt[:, 0])
@@ -289,12 +347,22 @@ class GreedyDecoder:
         return self.tokens
 
 
+    def check(self) -> None:
+        """Raise if a hand-off inside the persistent step kernel gave up (one read-back: call it where the tokens are consumed)."""
+        if self.path == "persistent" and int(self.err.item()) != 0:
+            raise RuntimeError("greedy decode: a hand-off of the persistent decode-step kernel timed out (not every workgroup of "
+                               "the launch was resident, or the device is shared); tokens of this run are invalid - re-run with "
+                               "path='launches'")
+
+
 @torch.no_grad()
 def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: bool = True, margins: bool = False,
-                  fused: bool = True, topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None):
+                  fused: bool = True, topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None, path: str = "auto"):
     """tokens (B, P + n_new) int64 [and per-position diagnostic margins].  fused=False uses the unfused
     projection + attention launches (same arithmetic, 2 more launches per layer); topk > 1 samples each token from the
-    softmax over the k largest logits on the device (same seed -> same ids)."""
-    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused, topk, seed, rules)
+    softmax over the k largest logits on the device (same seed -> same ids); path: "persistent" (all layers of a step in
+    one launch), "launches" (a launch per stage) or "auto"."""
+    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused, topk, seed, rules, path)
     toks = st.run(graph)
+    st.check()
     return (toks, st.margins) if margins else toks

@@ -83,12 +83,14 @@ class WhisperDecoder(nn.Module):
         return ops.linear(h.view(-1, h.shape[-1]), E, None, out_dtype=torch.float32).view(*x.shape, E.shape[0])
 
     @torch.no_grad()
-    def generate(self, memory: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, rules=None) -> Tensor:
+    def generate(self, memory: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, rules=None,
+                 path: str = "auto") -> Tensor:
         """Batched greedy decoding with a KV cache: (B, P) int64 prompt -> (B, P + max_new_tokens) ids.  ``rules``: a
-        generate.WhisperRules (token suppression, timestamp pairing / monotonicity) applied to the logits on the device."""
+        generate.WhisperRules (token suppression, timestamp pairing / monotonicity) applied to the logits on the device;
+        ``path``: "persistent" / "launches" / "auto" (generate.GreedyDecoder)."""
         from .generate import greedy_decode
 
-        return greedy_decode(self, memory, prompt, max_new_tokens, graph=graph, rules=rules)
+        return greedy_decode(self, memory, prompt, max_new_tokens, graph=graph, rules=rules, path=path)
 
 
 class Whisper(nn.Module):
@@ -105,9 +107,9 @@ class Whisper(nn.Module):
         return self.decoder(targets, self.encoder(x))
 
     @torch.no_grad()
-    def generate(self, x: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, rules=None) -> Tensor:
+    def generate(self, x: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, rules=None, path: str = "auto") -> Tensor:
         """log-mel (B, n_mels, T) + prompt ids (B, P) -> greedy ids (B, P + max_new_tokens)."""
-        return self.decoder.generate(self.encoder(x), prompt, max_new_tokens, graph=graph, rules=rules)
+        return self.decoder.generate(self.encoder(x), prompt, max_new_tokens, graph=graph, rules=rules, path=path)
 
     def load_openai_state_dict(self, state_dict) -> None:
         """OpenAI ``model_state_dict`` (e.g. ``torch.load(path, weights_only=True)["model_state_dict"]``)."""

@@ -43,12 +43,13 @@ class GPT2(nn.Module):
         return _lm_forward(self, x, self.norm)
 
     @torch.no_grad()
-    def generate(self, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, topk: int = 1, seed: int = 0) -> Tensor:
+    def generate(self, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, topk: int = 1, seed: int = 0,
+                 path: str = "auto") -> Tensor:
         """Batched decoding with a KV cache: (B, P) int64 prompt -> (B, P + max_new_tokens) ids; greedy (topk = 1) or
         top-k sampling on the device (softmax over the k largest logits; the same seed gives the same ids)."""
         from ..audio2text.generate import greedy_decode
 
-        return greedy_decode(self, None, prompt, max_new_tokens, graph=graph, topk=topk, seed=seed)
+        return greedy_decode(self, None, prompt, max_new_tokens, graph=graph, topk=topk, seed=seed, path=path)
 
     @staticmethod
     def from_hf(model_tag: str, *, pretrained=False, **kwargs) -> "GPT2":
