@@ -165,7 +165,7 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
             per[k] = {"launches_per_step": n_per_step,
                       "us_per_step": round(1e3 * sum(a.elapsed_time(b) for a, b, _ in v) / (len(v) / n_per_step), 2)}
         res["decode_kernels_eager"] = per
-        att = dlog.get("pm_dec_attention_fused", [])
+        att = dlog.get("pm_dec_attention_fused_v2") or dlog.get("pm_dec_attention_fused", [])
         cross = [(a, b) for a, b, ar in att if ar[18] == 0]  # self_attn == 0 <=> cross-attention block
         if cross:
             cross_ms = sum(a.elapsed_time(b) for a, b in cross)

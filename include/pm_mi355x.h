@@ -295,6 +295,13 @@ int pm_dec_sample_topk(const float* logits, int64_t ldl, int64_t V, int64_t k, u
                        const int64_t* prompt, int64_t P, int64_t* tok_cur, int64_t* tokens_out, int64_t Ttot, const void* emb,
                        const float* pos, float* x, int64_t d, int32_t* ticket, int64_t B, void* stream);
 
+/* pm_dec_attention_fused with the whole K stream of a (sequence, head) requested up front by seven of the workgroup's
+ * eight waves while the eighth loads and normalises the row (csrc/decode_persist.hip): same arguments, lk_max <= 2048. */
+int pm_dec_attention_fused_v2(const float* x, int64_t d, const float* gamma, const float* beta, float eps, const void* w,
+                              const float* bias, void* kc, void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
+                              const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, float* out, int64_t B, int64_t H,
+                              int self_attn, void* stream);
+
 /* One layer of the persistent decode step (pm_dec_layers): device pointers into the decoder's weights (bf16 matrices,
  * row-major (out, in); f32 vectors) and its per-run buffers.  Layer algebra: transformer.py:96-100 (pre-norm).
  * w_q == NULL: no cross-attention block (decoder-only language models). */

@@ -30,6 +30,7 @@ namespace {
 
 constexpr int PS_THREADS = 512;
 constexpr int PS_MAXK = 2048;  // keys an attention task can park scores for (S and Tmax)
+constexpr int PS_MAXL = 48;    // layers (the table is staged in LDS)
 constexpr unsigned PS_SPIN_MAX = 1u << 17;
 
 struct PsArgs {
@@ -340,7 +341,21 @@ __device__ __forceinline__ void ps_attn_task(const PsArgs& p, PsLds& s, int b, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   lds_barrier();  // the stores above are drained before anyone signals; also fences s.* reuse by the next task
-  if (tid == 0) __hip_atomic_fetch_add(sig_c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && sig_c) __hip_atomic_fetch_add(sig_c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The same block as its own launch (the launch-per-stage step form): one workgroup per (sequence, head), nothing to wait
+// for, nobody to signal.  Against decode.hip's dec_attn_fused_kernel it keeps the whole K stream (and the head of V) in
+// flight from the first instruction - that kernel had 4 passes (32 KB per CU) in flight per round trip, which is what
+// held a CU at ~17 GB/s - without putting the row behind it: wave 0, which loads and normalises the row, requests no K / V.
+template <bool SELF, int NCH, int KREG, int VREG>
+__global__ __launch_bounds__(PS_THREADS) void dec_attn_v2_kernel(PsArgs p, const float* gamma, const float* beta, float eps,
+                                                                 const bf16* Wp, const float* bp, bf16* Kc, bf16* Vc, int64_t sb,
+                                                                 int64_t sh, int64_t sk) {
+  __shared__ PsLds s;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int tpos = SELF ? *p.pos_ptr : 0;
+  ps_attn_task<SELF, NCH, KREG, VREG>(p, s, b, h, tpos, gamma, beta, eps, Wp, bp, Kc, Vc, sb, sh, sk, nullptr, 0, nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -535,7 +550,13 @@ template <int NCH, int NSTEP>
 __global__ __launch_bounds__(PS_THREADS) void dec_layers_kernel(PsArgs p) {
   __shared__ PsLds s;
   __shared__ float gb[2 * 128 * NSTEP];
+  __shared__ pm_dec_layer_t tabL[PS_MAXL];
   if (ld_agent(p.err) != 0) return;  // a hand-off of an earlier launch gave up: drain at once, the host raises
+  // the layer table goes to LDS once: read through the kernel-argument pointer where it is used, every stage paid the
+  // scalar loads' round trips in its prologue
+  for (int i = threadIdx.x; i < p.n_layers * (int)(sizeof(pm_dec_layer_t) / 4); i += PS_THREADS)
+    ((int*)tabL)[i] = ((const int*)p.tab)[i];
+  lds_barrier();
   const int t = *p.pos_ptr;
   const int epoch = t + 1;
   const int G = gridDim.x, w = blockIdx.x;
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(PS_THREADS) void dec_layers_kernel(PsArgs p) {
   constexpr int KREG_S = NCH <= 8 ? 8 : 4;
 
   for (int l = 0; l < p.n_layers; ++l) {
-    const pm_dec_layer_t& L = p.tab[l];
+    const pm_dec_layer_t& L = tabL[l];
     int* c = p.cnt + l * 24;
     const int* prev = l > 0 ? c - 4 : nullptr;  // stage 5 of the layer before
     // ---- S0: self-attention block
@@ -624,6 +645,42 @@ int launch_layers(const PsArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
+/* pm_dec_attention_fused (same arguments, same result up to the summation order of the row's LayerNorm statistics) on the
+ * persistent step's attention block: lk_max <= 2048. */
+extern "C" int pm_dec_attention_fused_v2(const float* x, int64_t d, const float* gamma, const float* beta, float eps,
+                                         const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
+                                         int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
+                                         int64_t lk_max, float* out, int64_t B, int64_t H, int self_attn, void* stream) {
+  if (!x || !gamma || !beta || !w || !kc || !vc || !out || B <= 0 || H <= 0 || d <= 0 || lk_max <= 0) return PM_EINVAL;
+  if (d % 64 || d > 1280 || lk_max > PS_MAXK) return PM_EUNSUPPORTED;
+  if (self_attn ? !pos_ptr : lk_const <= 0) return PM_EINVAL;
+  if ((stride_b | stride_h | stride_k) % 8) return PM_EALIGN;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)out) & 15) return PM_EALIGN;
+  if (B * H > 0x7fffffff) return PM_EINVAL;
+  PsArgs a{};
+  a.B = (int)B; a.d = (int)d; a.H = (int)H; a.S = (int)lk_const; a.pos_ptr = (const int*)pos_ptr;
+  a.x = const_cast<float*>(x); a.att = out;
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (int)(d / 64);
+#define PM_AV2(SELF_, NCH_, KR_, VR_)                                                                                       \
+  hipLaunchKernelGGL((dec_attn_v2_kernel<SELF_, NCH_, KR_, VR_>), dim3((unsigned)(B * H)), dim3(PS_THREADS), 0, st, a, gamma, \
+                     beta, eps, (const bf16*)w, bias, (bf16*)kc, (bf16*)vc, stride_b, stride_h, stride_k)
+  if (self_attn) {
+    if (nch <= 8) PM_AV2(true, 8, 8, 8);
+    else if (nch <= 12) PM_AV2(true, 12, 8, 8);
+    else if (nch <= 16) PM_AV2(true, 16, 8, 8);
+    else PM_AV2(true, 20, 8, 8);
+  } else {
+    if (nch <= 8) PM_AV2(false, 8, 27, 14);
+    else if (nch <= 12) PM_AV2(false, 12, 27, 12);
+    else if (nch <= 16) PM_AV2(false, 16, 27, 8);
+    else PM_AV2(false, 20, 27, 4);
+  }
+#undef PM_AV2
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
 /* number of workgroups pm_dec_layers launches (one per CU): sizes nothing the caller allocates, exposed for tests */
 extern "C" int pm_dec_layers_grid(void) { return dev_info().cus; }
 
@@ -633,6 +690,7 @@ extern "C" int pm_dec_layers(const pm_dec_layer_t* layers, int64_t n_layers, int
                              void* stream) {
   if (!layers || !pos_ptr || !x || !att || !h || !counters || !split_ws || !split_cnt || !err) return PM_EINVAL;
   if (n_layers <= 0 || B <= 0 || d <= 0 || H <= 0 || S < 0 || Tmax <= 0 || hid <= 0 || ldh < hid) return PM_EINVAL;
+  if (n_layers > PS_MAXL) return PM_EUNSUPPORTED;
   if (B > 64 || d % 64 || d > 1280 || H * 64 != d || S > PS_MAXK || Tmax > PS_MAXK || ldh % 4 || hid % 32) return PM_EUNSUPPORTED;
   if (act != PM_ACT_NONE && act != PM_ACT_GELU && act != PM_ACT_GELU_TANH) return PM_EUNSUPPORTED;
   if (k_split < 1 || k_split > 8 || hid / 32 < k_split) return PM_EINVAL;

@@ -20,7 +20,11 @@ from .._hip import DecLayer, check, lib, ops
 from ..transformer import _f32
 
 
-PERSISTENT_BY_DEFAULT = True  # path="auto": the persistent layer kernel wherever it applies
+# path="auto" = the launch-per-stage list.  Measured (tools/decode_paths_bench.py, MI355X, batch 32, us per step): Whisper-base 461
+# launches / 623 persistent, small 1044 / 1665, large-v2 4476 / 7160 - inside one launch a stage boundary costs MORE than a
+# kernel boundary (poll + barrier + sc1 round trips ~4-5 us against ~1.5 us + first loads), exactly what
+# cdna_hip_programming.md 5.6 reports for latency-bound phases.  The persistent path stays selectable and tested.
+PERSISTENT_BY_DEFAULT = False
 
 
 def _ptr(t: Tensor | None):
@@ -96,6 +100,9 @@ class GreedyDecoder:
         self.path = "persistent" if (path == "persistent" or (path == "auto" and persist_ok and PERSISTENT_BY_DEFAULT)) else "launches"
         persistent = self.path == "persistent"
         table = []
+        # the attention block with the whole K stream in flight from the start (decode_persist.hip): opt-in, for A/B runs
+        v2 = os.environ.get("PM_DEC_ATTN_V2", "0") != "0" and max(S, self.Ttot) <= 2048  # measured slower (527 vs 461 us per step): off
+        attn_fused = L.pm_dec_attention_fused_v2 if v2 else L.pm_dec_attention_fused
         self.B, self.P, self.n_steps = B, P, self.Ttot - 1
         Tmax = self.Ttot
         f32 = dict(dtype=torch.float32, device=dev)
@@ -183,7 +190,7 @@ class GreedyDecoder:
                                vc=vc.data_ptr(), w_so=sa.out_proj.weight.data_ptr(), b_so=_ptr(bo), sa_eps=float(layer.sa_norm.eps))
                 table.append(ent)
             elif fuse_self:  # LN + q/k/v projection + cache append + attention in one launch per layer
-                add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
+                add(attn_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
                     wqkv.data_ptr(), _ptr(bqkv), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64, self.pos.data_ptr(),
                     0, Tmax, self.att.data_ptr(), B, H, 1, None)
             else:
@@ -210,7 +217,7 @@ class GreedyDecoder:
                     ent.w_q, ent.b_q, ent.cross_kv = ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr()
                     ent.w_co, ent.b_co = ca.out_proj.weight.data_ptr(), _ptr(bo)
                 elif fuse_cross:
-                    add(L.pm_dec_attention_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
+                    add(attn_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
                         ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
                         2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
                 else:

@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 for k, v in log.items():
     per = {}
     for a, b, args in v:
-        key = (args[12], args[13], args[14]) if k == "pm_dec_linear" else (args[10], args[11]) if k == "pm_dec_linear_ksplit" else (args[18],) if k == "pm_dec_attention_fused" else ()
+        key = (args[12], args[13], args[14]) if k == "pm_dec_linear" else (args[10], args[11]) if k == "pm_dec_linear_ksplit" else (args[18],) if k.startswith("pm_dec_attention_fused") else ()
         per.setdefault(key, []).append(a.elapsed_time(b) * 1e3)
     for key, ts in per.items():
         print(f"{k:26s} {str(key):22s} n={len(ts):4d} avg {sum(ts)/len(ts):7.1f} us")

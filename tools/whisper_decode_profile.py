@@ -32,7 +32,7 @@ for k, v in log.items():
     per = {}
     for a, b, args in v:
         key = (args[12], args[13], args[14]) if k == "pm_dec_linear" else (args[10], args[11]) if k == "pm_dec_linear_ksplit" else (
-            "self" if args[18] else "cross",) if k == "pm_dec_attention_fused" else ()
+            "self" if args[18] else "cross",) if k.startswith("pm_dec_attention_fused") else ()
         per.setdefault(key, []).append(a.elapsed_time(b) * 1e3)
     nsteps = len(range(0, dec.n_steps, 8))
     for key, ts in per.items():
