@@ -54,6 +54,17 @@ int pm_linear_bf16_ex(const void* x, int64_t ldx, int64_t x_rows_per_batch, int6
                       int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
                       void* stream);
 
+/* pm_linear_bf16_ln with a caller-owned workspace: pm_linear_ws_bytes() bytes, 16-byte aligned, its first 4096 bytes zero
+ * before the first call and left alone afterwards.  With it the dispatcher may deal a GEMM's K steps out as ONE stream over
+ * the persistent workgroups ("stream-K", csrc/linear_bf16_sk.hip) where whole 256 x 256 tiles would leave the last round
+ * badly filled (M = 50432: N = 768 is 2.31 rounds, N = 3072 9.23); tiles shared by two workgroups are combined in fp32
+ * through the workspace, deterministically.  One workspace serves one stream at a time.  ws == NULL: pm_linear_bf16_ln. */
+int pm_linear_bf16_ws(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w, int64_t ldw,
+                      const float* bias, const void* resid, int64_t ldr, int resid_dtype, int64_t resid_period, void* y,
+                      int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act, const float* ln_stats,
+                      const float* ln_s, float* ln_row_out, void* ws, int64_t ws_bytes, void* stream);
+int64_t pm_linear_ws_bytes(void);
+
 /* LayerNorm folded into the GEMMs around it (pre-norm blocks, transformer.py:124-125: x + f(LN(x))).
  * pm_linear_bf16_ln = pm_linear_bf16_ex plus
  *  - ln_stats (M, 2) f32 [mean, rstd per input row] and ln_s (N) f32: y = act(rstd*(x w'^T - mean*ln_s) + bias) + resid,

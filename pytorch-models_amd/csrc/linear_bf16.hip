@@ -25,6 +25,12 @@ int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_ba
                                int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
                                int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, hipStream_t st);
 bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act);
+// linear_bf16_sk.hip
+int pm_linear_bf16_sk_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
+                             int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
+                             int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, void* ws, hipStream_t st);
+bool pm_linear_bf16_sk_applies(int64_t M, int64_t N, int64_t K, int act);
+int64_t pm_linear_sk_ws_bytes();
 
 namespace {
 
@@ -496,9 +502,20 @@ int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int6
 // chip).  Cost = rounds over the resident workgroups x work per tile / relative rate: 256 x 256 tiles on 256 workgroups at
 // 1.25, 256 x 128 on 256 at 1.0, 128 x 128 on 512 (two per CU) at 0.7 with a partly filled last round costing
 // 0.3 + 0.7 * fill of a full one (co-resident workgroups speed up when their neighbour has finished).
-enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3 };
-static int pm_linear_pick_kernel(int64_t M, int64_t N, bool persist_ok, bool wide_ok, bool has_resid) {
-  static const int forced = [] { const char* e = getenv("PM_GEMM_KERNEL"); return e ? atoi(e) : 0; }();  // experiments: 1 / 2 / 3
+// Stream-K form of the 256 x 256 kernel (linear_bf16_sk.hip): no round quantisation - its cost is the exact tile count over 256
+// plus the partial-tile exchange (one 256 KiB store and load per workgroup, ~a quarter of a K = 768 tile), taken when that
+// beats the best whole-tile kernel by 3 % (QKV at 6.93 rounds stays whole-tile; linear1 at 9.23, out_proj / linear2 at 2.31 move).
+enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3, PM_K_SK = 4 };
+static int pm_linear_pick_kernel(int64_t M, int64_t N, int64_t K, bool persist_ok, bool wide_ok, bool sk_ok, bool has_resid) {
+  static const int forced = [] { const char* e = getenv("PM_GEMM_KERNEL"); return e ? atoi(e) : 0; }();  // experiments: 1 .. 4
+  // OFF unless PM_GEMM_STREAMK=1: measured on MI355X (tools/sk_check.py, us, whole-tile 256 x 256 kernel -> stream-K): out_proj
+  // 96 -> 118, linear2 316 -> 339, linear1 + GELU 335 -> 352, QKV 196 -> 224, 8192^3 851 -> 935.  The balance is real (every
+  // workgroup issues the same MFMAs) but each launch moves 64 MB of fp32 partial tiles out and back (one per workgroup:
+  // ~25 us), and contiguous per-workgroup ranges lose the L2 sharing of interleaved neighbouring tiles (-10 % in the K loop).
+  static const bool use_sk = [] { const char* e = getenv("PM_GEMM_STREAMK"); return e && atoi(e) != 0; }();
+  if (!use_sk && forced != PM_K_SK) sk_ok = false;
+  if (forced == PM_K_SK && sk_ok) return PM_K_SK;
+  if (forced && forced != PM_K_SK) sk_ok = false;
   if (forced == PM_K_WIDE && wide_ok) return PM_K_WIDE;
   if (forced == PM_K_PERSIST && persist_ok) return PM_K_PERSIST;
   if (forced == PM_K_SMALL) return PM_K_SMALL;
@@ -514,6 +531,9 @@ static int pm_linear_pick_kernel(int64_t M, int64_t N, bool persist_ok, bool wid
   const double cs = rounds(ts, 512, 0.3) * 2.0 / (has_resid ? 0.65 : 0.7);
   const double cp = persist_ok ? rounds(tp, 256, 1.0) * 2.0 : 1e30;
   const double cw = wide_ok ? rounds(tw, 256, 1.0) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
+  const double csk = sk_ok ? (tw / 256.0 + 0.25 * 768.0 / (double)K) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
+  const double best = cw < cp ? (cw < cs ? cw : cs) : (cp < cs ? cp : cs);
+  if (csk < 0.97 * best) return PM_K_SK;
   if (cw <= cp && cw <= cs) return PM_K_WIDE;
   return cp <= cs ? PM_K_PERSIST : PM_K_SMALL;
 }
@@ -521,7 +541,7 @@ static int pm_linear_pick_kernel(int64_t M, int64_t N, bool persist_ok, bool wid
 static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                        int64_t ldw, const float* bias, const void* resid, int64_t ldr, int resid_dtype,
                        int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
-                       PmLnFold ln, void* stream) {
+                       PmLnFold ln, void* stream, void* ws = nullptr, int64_t ws_bytes = 0) {
   if (!x || !w || !y || M < 0 || N <= 0 || K <= 0) return PM_EINVAL;
   const bool want_ln = ln.stats || ln.row_out;
   if ((ln.stats == nullptr) != (ln.s == nullptr)) return PM_EINVAL;
@@ -539,19 +559,30 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   if (M > (1 << 30) || N > (1 << 30) || K > (1 << 30) || resid_period > (1 << 30)) return PM_EINVAL;
   hipStream_t st0 = (hipStream_t)stream;
   const bool out_vec16 = N % 8 == 0 && ldy % 8 == 0 && !((uintptr_t)y & 15);
-  bool wide_ok = y_dtype == PM_BF16 && vec_ok && out_vec16 && !(resid && resid_dtype != PM_BF16) &&
-                 !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) && pm_linear_bf16_wide_applies(M, N, K, act) && !ln.row_out &&
-                 // the wide kernel keeps 32-bit element offsets per operand
-                 (x_rows_per_batch > 0 ? (M / x_rows_per_batch + 1) * x_batch_stride : M * ldx) < (1LL << 32) && N * ldw < (1LL << 32);
+  const bool wide_base = y_dtype == PM_BF16 && vec_ok && out_vec16 && !(resid && resid_dtype != PM_BF16) &&
+                         !(resid && (ldr % 8 || ((uintptr_t)resid & 15))) &&
+                         // the 256 x 256 kernels keep 32-bit element offsets per operand
+                         (x_rows_per_batch > 0 ? (M / x_rows_per_batch + 1) * x_batch_stride : M * ldx) < (1LL << 32) &&
+                         N * ldw < (1LL << 32);
+  bool wide_ok = wide_base && pm_linear_bf16_wide_applies(M, N, K, act) && !ln.row_out;
+  const bool sk_ok = wide_base && ws && ws_bytes >= pm_linear_sk_ws_bytes() && !((uintptr_t)ws & 15) &&
+                     pm_linear_bf16_sk_applies(M, N, K, act) && !(ln.row_out && act != PM_ACT_NONE);
   const bool persist_ok = (K % BK == 0) && (M >= 4096) && (y_dtype == PM_F32 || !vec_ok || out_vec16);
   const bool staged_ok = persist_ok && y_dtype == PM_BF16 && vec_ok && !(resid && resid_dtype == PM_F32);
   int kernel;
   if (want_ln) {  // the LayerNorm fold lives in the persistent kernels' staged epilogues (row partials: 256 x 128 only)
     if (!staged_ok) return PM_EUNSUPPORTED;
-    kernel = pm_linear_pick_kernel(M, N, true, wide_ok, resid != nullptr);
+    kernel = pm_linear_pick_kernel(M, N, K, true, wide_ok, sk_ok, resid != nullptr);
     if (kernel == PM_K_SMALL) kernel = PM_K_PERSIST;
   } else {
-    kernel = pm_linear_pick_kernel(M, N, persist_ok, wide_ok, resid != nullptr);
+    kernel = pm_linear_pick_kernel(M, N, K, persist_ok, wide_ok, sk_ok, resid != nullptr);
+  }
+  if (kernel == PM_K_SK) {
+    const int rck = pm_linear_bf16_sk_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
+                                             ldy, M, N, K, act, ln, ws, st0);
+    if (rck != PM_OK) return rck;
+    PM_CHECK_LAUNCH();
+    return PM_OK;
   }
   if (kernel == PM_K_WIDE) {
     const int rcw = pm_linear_bf16_wide_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
@@ -608,6 +639,23 @@ extern "C" int pm_linear_bf16_ln(const void* x, int64_t ldx, int64_t x_rows_per_
   return linear_impl(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_dtype, resid_period, y, ldy,
                      y_dtype, M, N, K, act, ln, stream);
 }
+
+/* pm_linear_bf16_ln with a caller-owned workspace (pm_linear_ws_bytes() bytes, 16-byte aligned, its first 4096 bytes ZERO
+ * before the first call and never written by the caller afterwards): with it the dispatcher may deal a GEMM's K steps out
+ * as one stream over the persistent workgroups (csrc/linear_bf16_sk.hip) when whole tiles would leave the last round
+ * badly filled.  One workspace serves one stream at a time (calls that may overlap need their own).  ws == NULL: as
+ * pm_linear_bf16_ln. */
+extern "C" int pm_linear_bf16_ws(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
+                                 const void* w, int64_t ldw, const float* bias, const void* resid, int64_t ldr,
+                                 int resid_dtype, int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M,
+                                 int64_t N, int64_t K, int act, const float* ln_stats, const float* ln_s,
+                                 float* ln_row_out, void* ws, int64_t ws_bytes, void* stream) {
+  PmLnFold ln{ln_stats, ln_s, ln_row_out};
+  return linear_impl(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_dtype, resid_period, y, ldy,
+                     y_dtype, M, N, K, act, ln, stream, ws, ws_bytes);
+}
+
+extern "C" int64_t pm_linear_ws_bytes(void) { return pm_linear_sk_ws_bytes(); }
 
 namespace {
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,

@@ -26,6 +26,8 @@ SIGNATURES = {
     "pm_linear_bf16": ([_p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
     "pm_linear_bf16_ex": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
     "pm_linear_bf16_ln": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p, _p, _p, _p], c_int),
+    "pm_linear_bf16_ws": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p, _p, _p, _p, _l, _p], c_int),
+    "pm_linear_ws_bytes": ([], c_int64),
     "pm_ln_stats_finalize": ([_p, _p, _l, _l, _f, _p], c_int),
     "pm_linear_ln_supported": ([_l, _l, _l, _i, _i], c_int),
     "pm_stft_mel": ([_p, _l, _l, _l, _p, _p, _l, _l, _l, _i, _p, _p, _p, _l, _p, _p, _p], c_int),

@@ -3,6 +3,8 @@ current torch stream, raise on a non-zero status.  PyTorch is used for device me
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -98,6 +100,32 @@ def ln_stats_finalize(partials: Tensor, N: int, eps: float) -> Tensor:
     return stats
 
 
+_GEMM_WS: dict = {}
+
+
+def gemm_workspace(device: torch.device) -> tuple[int, int]:
+    """(pointer, bytes) of the stream-K workspace of (device, current stream): pm_linear_ws_bytes() bytes allocated once per
+    stream that ever runs a large GEMM, ticket block zeroed (the kernels leave it zero).  Large GEMMs (M >= 4096) only:
+    small problems never take the stream-K kernel, so they never allocate it."""
+    key = (device.index, _stream())
+    hit = _GEMM_WS.get(key)
+    if hit is None:
+        n = int(lib().pm_linear_ws_bytes())
+        buf = torch.empty(n, dtype=torch.uint8, device=device)
+        buf[:4096].zero_()
+        hit = _GEMM_WS[key] = (buf, n)
+    return hit[0].data_ptr(), hit[1]
+
+
+_USE_STREAMK = os.environ.get("PM_GEMM_STREAMK", "0") != "0" or os.environ.get("PM_GEMM_KERNEL") == "4"
+
+
+def _ws_args(M: int, device: torch.device):
+    """The stream-K kernel is opt-in (PM_GEMM_STREAMK=1: measured slower than whole tiles on this repo's shapes, see
+    csrc/linear_bf16.hip): without it no workspace is allocated and pm_linear_bf16_ws behaves as pm_linear_bf16_ln."""
+    return gemm_workspace(device) if (_USE_STREAMK and M >= 4096) else (None, 0)
+
+
 def _linear_bytes(x: Tensor, w: Tensor, out: Tensor, resid: Tensor | None) -> float:
     """algorithmic bytes of one GEMM launch: every operand once (bias and LayerNorm-fold vectors are noise)"""
     n = x.numel() * x.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size()
@@ -129,20 +157,17 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none
             _need(ln_stats.shape == (M, 2) and ln_stats.dtype == torch.float32 and ln_stats.is_contiguous()
                   and ln_s.dtype == torch.float32 and ln_s.numel() == N and ln_s.is_contiguous(), "linear: bad LayerNorm-fold operands")
         rows = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device) if want_row_stats else None
-        rc = _launch("linear_bf16", (2.0 * M * N * K, _linear_bytes(x, w, out, resid)), lambda: lib().pm_linear_bf16_ln(
-            x.data_ptr(), x.stride(0), 0, 0, w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
-            resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
-            _dt(resid) if resid is not None else 0, 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act],
-            ln_stats.data_ptr() if ln_stats is not None else None, ln_s.data_ptr() if ln_s is not None else None,
-            rows.data_ptr() if rows is not None else None, _stream()))
-        check(rc, f"pm_linear_bf16_ln(M={M}, N={N}, K={K})")
-        return (out, rows) if want_row_stats else out
-    rc = _launch("linear_bf16", (2.0 * M * N * K, _linear_bytes(x, w, out, resid)), lambda: lib().pm_linear_bf16(
-        x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
+    else:
+        rows = None
+    ws, ws_bytes = _ws_args(M, x.device)
+    rc = _launch("linear_bf16", (2.0 * M * N * K, _linear_bytes(x, w, out, resid)), lambda: lib().pm_linear_bf16_ws(
+        x.data_ptr(), x.stride(0), 0, 0, w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
         resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0,
-        _dt(resid) if resid is not None else 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream()))
-    check(rc, f"pm_linear_bf16(M={M}, N={N}, K={K})")
-    return out
+        _dt(resid) if resid is not None else 0, 0, out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act],
+        ln_stats.data_ptr() if ln_stats is not None else None, ln_s.data_ptr() if ln_s is not None else None,
+        rows.data_ptr() if rows is not None else None, ws, ws_bytes, _stream()))
+    check(rc, f"pm_linear_bf16_ws(M={M}, N={N}, K={K})")
+    return (out, rows) if want_row_stats else out
 
 
 def layernorm(x: Tensor, gamma: Tensor | None, beta: Tensor | None, eps: float, out_dtype: torch.dtype | None = None,
@@ -284,12 +309,13 @@ def linear_strided(x: Tensor, *, M: int, K: int, row_stride: int, rows_per_batch
         out = torch.empty((M, N), dtype=out_dtype, device=x.device)
     else:  # e.g. a column slice of a wider matrix (one group of a grouped conv)
         _need(out.is_cuda and out.shape == (M, N) and out.stride(1) == 1, "linear_strided: out must be (M, N) with unit column stride")
-    rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16_ex(
+    ws, ws_bytes = _ws_args(M, out.device)
+    rc = _launch("linear_bf16", 2.0 * M * N * K, lambda: lib().pm_linear_bf16_ws(
         x.data_ptr(), row_stride, rows_per_batch, batch_stride, w.data_ptr(), w.stride(0),
         bias.data_ptr() if bias is not None else None, resid.data_ptr() if resid is not None else None,
         resid.stride(0) if resid is not None else 0, _dt(resid) if resid is not None else 0, resid_period,
-        out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], _stream()))
-    check(rc, f"pm_linear_bf16_ex(M={M}, N={N}, K={K})")
+        out.data_ptr(), out.stride(0), _dt(out), M, N, K, ACT[act], None, None, None, ws, ws_bytes, _stream()))
+    check(rc, f"pm_linear_bf16_ws(M={M}, N={N}, K={K})")
     return out
 
 

@@ -6,6 +6,7 @@ require |got - want| <= 1e-2 * |want| + 1e-2 * rms(want) for bf16 outputs, and 1
 fp32 outputs (accumulation-order differences only).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -282,3 +283,47 @@ def test_vit_tokens(ops, N, img, d, cls):
                          sd["pe"].view(L, d).cuda(), sd["cls_token"].view(-1).cuda() if cls else None, P)
     assert got.shape == (N, L + int(cls), d)
     close_bf16(got, want)
+
+
+def test_stream_k_gemm_matches_whole_tiles(monkeypatch):
+    """csrc/linear_bf16_sk.hip (opt-in: PM_GEMM_KERNEL=4 forces it): K steps dealt out as one stream, tiles shared by two
+    workgroups combined in fp32 through the workspace.  Same operands -> results within bf16 rounding of the whole-tile
+    kernel's (a split tile sums its two K ranges separately), deterministic, tickets left at zero; with the LayerNorm fold's
+    row partials and a residual as out_proj / linear2 use it."""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys, torch
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "pytorch-models_amd")]
+from pytorch_models._hip import ops
+torch.manual_seed(1)
+for (M, N, K, act, resid, rows) in [(16000, 768, 768, "none", True, True), (9000, 1536, 320, "gelu", False, False), (33000, 512, 1024, "none", True, False)]:
+    x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda")
+    r = torch.randn(M, N, device="cuda").to(torch.bfloat16) if resid else None
+    got = ops.linear(x, w, b, act=act, resid=r, want_row_stats=rows)
+    got, st = got if rows else (got, None)
+    ref = x.float() @ w.float().T + b
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if resid:
+        ref = ref + r.float()
+    err = (got.float() - ref).abs().max().item()
+    assert err <= 2 ** -7 * ref.abs().max().item() + 1e-2, err
+    again = ops.linear(x, w, b, act=act, resid=r, want_row_stats=rows)
+    again = again[0] if rows else again
+    assert torch.equal(got, again)
+    if rows:
+        blk = got.float().view(M, N // 64, 64)
+        torch.testing.assert_close(st[..., 0], blk.sum(-1), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(st[..., 1], (blk * blk).sum(-1), rtol=1e-4, atol=1e-3)
+    ws = list(ops._GEMM_WS.values())
+    assert ws and int(ws[0][0][:4096].view(torch.int32).abs().sum()) == 0  # every ticket back at zero
+print("ok")
+"""
+    env = dict(os.environ, PM_GEMM_KERNEL="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
