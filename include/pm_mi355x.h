@@ -54,6 +54,15 @@ int pm_linear_bf16_ex(const void* x, int64_t ldx, int64_t x_rows_per_batch, int6
                       int64_t resid_period, void* y, int64_t ldy, int y_dtype, int64_t M, int64_t N, int64_t K, int act,
                       void* stream);
 
+/* nn.Linear in fp32, for modules whose parameters are fp32 (the reference's default dtype: tests/image/test_vit.py:45 asks
+ * 2e-5, tests/audio2text/test_whisper.py:45 5e-5) and for the exact Whisper pipeline: y = act(x w^T + bias) + resid, all
+ * operands f32, on the f32-input MFMA (exact fp32 products and accumulation; csrc/linear_f32.hip).  Addressing as
+ * pm_linear_bf16_ex (two-level x rows: Conv1d / Conv2d windows as GEMM rows; periodic resid rows: a position table).
+ * ldx, ldw multiples of 4, x and w 16-byte aligned; every activation of the table above. */
+int pm_linear_f32(const float* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const float* w, int64_t ldw,
+                  const float* bias, const float* resid, int64_t ldr, int64_t resid_period, float* y, int64_t ldy, int64_t M,
+                  int64_t N, int64_t K, int act, void* stream);
+
 /* pm_linear_bf16_ln with a caller-owned workspace: pm_linear_ws_bytes() bytes, 16-byte aligned, its first 4096 bytes zero
  * before the first call and left alone afterwards.  With it the dispatcher may deal a GEMM's K steps out as ONE stream over
  * the persistent workgroups ("stream-K", csrc/linear_bf16_sk.hip) where whole 256 x 256 tiles would leave the last round
@@ -172,6 +181,14 @@ int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int64_t q_strid
                               const float* bias, int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q,
                               void* stream);
 
+/* pm_attention_generic_bf16 on fp32 operands (strides in elements, multiples of 4; o 16-byte aligned): the attention of
+ * fp32 modules and of the exact Whisper pipeline - fp32 in, fp32 arithmetic, fp32 out. */
+int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int64_t q_stride_t, const float* k, int64_t k_stride_b,
+                             int64_t k_stride_t, const float* v, int64_t v_stride_b, int64_t v_stride_t, float* o,
+                             int64_t o_stride_b, int64_t o_stride_t, int64_t B, int64_t H, int64_t Lq, int64_t Lk,
+                             int64_t head_dim, int causal, const float* bias, int64_t bias_stride_b, int64_t bias_stride_h,
+                             int64_t bias_stride_q, void* stream);
+
 /* ViT token assembly (vit.py:78-81): Conv2d(3, d, P, stride P) on fp32 NCHW images, flatten,
  * transpose, + pe, prepend cls - im2col-free.  imgs: f32 (N,3,Himg,Wimg); w: bf16 (d, 3*P*P)
  * (the Conv2d weight viewed 2-D); bias: f32 (d); pe: f32 (L, d); cls: f32 (d) or NULL;
@@ -223,6 +240,9 @@ int pm_whisper_stem1(const float* x, const void* w, const float* bias, void* out
  * out: bf16 | f32 (B, L, d). */
 int pm_embed_tokens(const int64_t* tokens, const void* emb, const float* pos, void* out, int out_dtype, int64_t B,
                     int64_t L, int64_t pos0, int64_t d, int64_t V, void* stream);
+/* the same from an fp32 table into fp32 rows (modules whose parameters are fp32) */
+int pm_embed_tokens_f32(const int64_t* tokens, const float* emb, const float* pos, float* out, int64_t B, int64_t L,
+                        int64_t pos0, int64_t d, int64_t V, void* stream);
 
 /* ---- KV-cached greedy decode step (no reference counterpart: README.md:86 lists Whisper decoding as TODO; the
  * semantics follow pytorch_models/text/generator.py:23-35 over transformer.py:96-100 and whisper.py:47-53).

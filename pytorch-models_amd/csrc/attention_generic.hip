@@ -10,10 +10,26 @@ namespace {
 
 constexpr int GQ = 8, GMAXK = 2048, GMAXD = 128;
 
-__global__ __launch_bounds__(256) void attn_generic_kernel(const bf16* __restrict__ Q, int64_t qsb, int64_t qst,
-                                                           const bf16* __restrict__ K, int64_t ksb, int64_t kst,
-                                                           const bf16* __restrict__ V, int64_t vsb, int64_t vst,
-                                                           bf16* __restrict__ O, int64_t osb, int64_t ost, int H, int Lq,
+// T = bf16 (the head dims the MFMA kernel does not cover) or float (modules whose parameters are fp32, and the exact
+// Whisper pipeline: the same fp32 arithmetic on fp32 operands, nothing rounded on the way in or out)
+template <typename T>
+__device__ __forceinline__ void ld8(const T* p, float (&o)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+  } else {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_kernel(const T* __restrict__ Q, int64_t qsb, int64_t qst,
+                                                           const T* __restrict__ K, int64_t ksb, int64_t kst,
+                                                           const T* __restrict__ V, int64_t vsb, int64_t vst,
+                                                           T* __restrict__ O, int64_t osb, int64_t ost, int H, int Lq,
                                                            int Lk, int hd, int nqb, int causal,
                                                            const float* __restrict__ bias, int64_t bsb, int64_t bsh,
                                                            int64_t bsq, float scale) {
@@ -24,9 +40,9 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const bf16* __restric
   const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb;
   const int h = bh % H, b = bh / H;
   const int q0 = qb * GQ;
-  const bf16* Qp = Q + (int64_t)b * qsb + (int64_t)h * hd;
-  const bf16* Kp = K + (int64_t)b * ksb + (int64_t)h * hd;
-  const bf16* Vp = V + (int64_t)b * vsb + (int64_t)h * hd;
+  const T* Qp = Q + (int64_t)b * qsb + (int64_t)h * hd;
+  const T* Kp = K + (int64_t)b * ksb + (int64_t)h * hd;
+  const T* Vp = V + (int64_t)b * vsb + (int64_t)h * hd;
 
   for (int i = tid; i < GQ * hd; i += 256) {
     const int qq = i / hd, dd = i - qq * hd;
@@ -39,12 +55,13 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const bf16* __restric
     float acc[GQ];
 #pragma unroll
     for (int qq = 0; qq < GQ; ++qq) acc[qq] = 0.f;
-    const bf16* kr = Kp + (int64_t)key * kst;
+    const T* kr = Kp + (int64_t)key * kst;
     for (int d0 = 0; d0 < hd; d0 += 8) {
-      const bf16x8 kv = *(const bf16x8*)(kr + d0);
+      float kv[8];
+      ld8(kr + d0, kv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float kf = (float)kv[e];
+        const float kf = kv[e];
 #pragma unroll
         for (int qq = 0; qq < GQ; ++qq) acc[qq] = fmaf(qs[qq * GMAXD + d0 + e], kf, acc[qq]);
       }
@@ -80,16 +97,30 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const bf16* __restric
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     for (int key = 0; key < Lk; ++key) {
       const float p = sc[qq * GMAXK + key];
-      const bf16x4 vv = *(const bf16x4*)(Vp + (int64_t)key * vst + d0);
+      float vv[4];
+      if constexpr (sizeof(T) == 2) {
+        const bf16x4 v4 = *(const bf16x4*)(Vp + (int64_t)key * vst + d0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = fmaf(p, (float)vv[e], o[e]);
+        for (int e = 0; e < 4; ++e) vv[e] = (float)v4[e];
+      } else {
+        const f32x4 v4 = *(const f32x4*)(Vp + (int64_t)key * vst + d0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = v4[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaf(p, vv[e], o[e]);
     }
     const int qi = q0 + qq;
     if (qi < Lq) {
-      bf16x4 ov;
+      T* op = O + (int64_t)b * osb + (int64_t)qi * ost + (int64_t)h * hd + d0;
+      if constexpr (sizeof(T) == 2) {
+        bf16x4 ov;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = (bf16)(o[e] * inv_sum[qq]);
-      *(bf16x4*)(O + (int64_t)b * osb + (int64_t)qi * ost + (int64_t)h * hd + d0) = ov;
+        for (int e = 0; e < 4; ++e) ov[e] = (bf16)(o[e] * inv_sum[qq]);
+        *(bf16x4*)op = ov;
+      } else {
+        *(f32x4*)op = f32x4{o[0] * inv_sum[qq], o[1] * inv_sum[qq], o[2] * inv_sum[qq], o[3] * inv_sum[qq]};
+      }
     }
   }
 }
@@ -111,10 +142,34 @@ extern "C" int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int6
   const int nqb = (int)((Lq + GQ - 1) / GQ);
   const int64_t nblk = B * H * nqb;
   if (nblk > 0x7fffffff) return PM_EINVAL;
-  hipLaunchKernelGGL(attn_generic_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)q, q_stride_b,
+  hipLaunchKernelGGL(attn_generic_kernel<bf16>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)q, q_stride_b,
                      q_stride_t, (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t, (bf16*)o,
                      o_stride_b, o_stride_t, (int)H, (int)Lq, (int)Lk, (int)head_dim, nqb, causal, bias, bias_stride_b,
                      bias_stride_h, bias_stride_q, 1.0f / sqrtf((float)head_dim));
+  PM_CHECK_LAUNCH();
+  return PM_OK;
+}
+
+/* The same kernel on fp32 operands (strides in ELEMENTS): attention of modules whose parameters are fp32 and of the exact
+ * Whisper pipeline.  q, k, v, o f32 with unit last stride; head_dim % 8 == 0 (<= 128), Lk <= 2048; strides multiples of 4. */
+extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int64_t q_stride_t, const float* k,
+                                        int64_t k_stride_b, int64_t k_stride_t, const float* v, int64_t v_stride_b,
+                                        int64_t v_stride_t, float* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
+                                        int64_t H, int64_t Lq, int64_t Lk, int64_t head_dim, int causal, const float* bias,
+                                        int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream) {
+  if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0 || head_dim <= 0) return PM_EINVAL;
+  if (B == 0 || Lq == 0) return PM_OK;
+  if (head_dim % 8 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
+  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b | o_stride_t | o_stride_b) % 4) return PM_EALIGN;
+  if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return PM_EALIGN;
+  if (bias && bias_stride_q < Lk) return PM_EINVAL;
+  const int nqb = (int)((Lq + GQ - 1) / GQ);
+  const int64_t nblk = B * H * nqb;
+  if (nblk > 0x7fffffff) return PM_EINVAL;
+  hipLaunchKernelGGL(attn_generic_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, q, q_stride_b,
+                     q_stride_t, k, k_stride_b, k_stride_t, v, v_stride_b, v_stride_t, o, o_stride_b, o_stride_t, (int)H,
+                     (int)Lq, (int)Lk, (int)head_dim, nqb, causal, bias, bias_stride_b, bias_stride_h, bias_stride_q,
+                     1.0f / sqrtf((float)head_dim));
   PM_CHECK_LAUNCH();
   return PM_OK;
 }

@@ -143,7 +143,8 @@ __device__ __forceinline__ float apply_act(float x) {
   } else if constexpr (ACT == PM_ACT_RELU) {
     return fmaxf(x, 0.0f);
   } else if constexpr (ACT == PM_ACT_SILU) {
-    return x / (1.0f + __expf(-x));
+    if constexpr (PRECISE) return x / (1.0f + expf(-x));
+    else return x / (1.0f + __expf(-x));
   } else {
     return x;
   }

@@ -26,6 +26,8 @@ SIGNATURES = {
     "pm_linear_bf16": ([_p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
     "pm_linear_bf16_ex": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p], c_int),
     "pm_linear_bf16_ln": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p, _p, _p, _p], c_int),
+    "pm_linear_f32": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _l, _p, _l, _l, _l, _l, _i, _p], c_int),
+    "pm_attention_generic_f32": ([_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _l, _l, _l, _l, _l, _i, _p, _l, _l, _l, _p], c_int),
     "pm_linear_bf16_ws": ([_p, _l, _l, _l, _p, _l, _p, _p, _l, _i, _l, _p, _l, _i, _l, _l, _l, _i, _p, _p, _p, _p, _l, _p], c_int),
     "pm_linear_ws_bytes": ([], c_int64),
     "pm_ln_stats_finalize": ([_p, _p, _l, _l, _f, _p], c_int),
@@ -35,6 +37,7 @@ SIGNATURES = {
     "pm_logmel_finalize": ([_p, _p, _l, _l, _p], c_int),
     "pm_whisper_stem1": ([_p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_embed_tokens": ([_p, _p, _p, _p, _i, _l, _l, _l, _l, _l, _p], c_int),
+    "pm_embed_tokens_f32": ([_p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_dec_embed": ([_p, _p, _p, _p, _p, _l, _l, _l, _p], c_int),
     "pm_dec_linear": ([_p, _l, _p, _p, _f, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _p, _p, _l, _l, _l, _p, _p, _p, _p], c_int),
     "pm_dec_argmax_tile": ([_l], c_int),

@@ -170,6 +170,62 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none
     return (out, rows) if want_row_stats else out
 
 
+def linear_f32(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "none", resid: Tensor | None = None,
+               resid_period: int = 0, out: Tensor | None = None, M: int | None = None, K: int | None = None, row_stride: int | None = None,
+               rows_per_batch: int = 0, batch_stride: int = 0) -> Tensor:
+    """pm_linear_f32: y = act(x @ w.T + bias) + resid with every operand fp32 (exact-fp32 MFMA).  Plain form: x (M, K) with unit
+    column stride.  Window form (M, K, row_stride[, rows_per_batch, batch_stride] given): row m of the A operand is the K
+    contiguous floats at x + (m // rows_per_batch) * batch_stride + (m % rows_per_batch) * row_stride, as in linear_strided."""
+    _cuda(x, w, bias, resid, out)
+    _need(x.dtype == torch.float32 and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1, "linear_f32: x, w must be f32, w (N, K)")
+    if M is None:
+        _need(x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == w.shape[1], f"linear_f32: x {tuple(x.shape)} vs w {tuple(w.shape)}")
+        M, K, row_stride = x.shape[0], x.shape[1], x.stride(0)
+    else:
+        _need(K == w.shape[1] and row_stride is not None, "linear_f32: window form needs M, K, row_stride")
+    N = w.shape[0]
+    if bias is not None:
+        _need(bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N, "linear_f32: bias must be f32 (N)")
+    if resid is not None:
+        _need(resid.dtype == torch.float32 and resid.dim() == 2 and resid.shape[1] == N and resid.stride(1) == 1
+              and resid.shape[0] >= (resid_period or M), "linear_f32: resid must be f32 (rows, N)")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=w.device)
+    _need(out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1, "linear_f32: bad out")
+    rc = _launch("linear_f32", 2.0 * M * N * K, lambda: lib().pm_linear_f32(
+        x.data_ptr(), row_stride, rows_per_batch, batch_stride, w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None,
+        resid.data_ptr() if resid is not None else None, resid.stride(0) if resid is not None else 0, resid_period, out.data_ptr(),
+        out.stride(0), M, N, K, ACT[act], _stream()))
+    check(rc, f"pm_linear_f32(M={M}, N={N}, K={K})")
+    return out
+
+
+def attention_f32(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = False, bias: Tensor | None = None) -> Tensor:
+    """attention() on fp32 operands: q (B, Lq, H*hd), k / v (B, Lk, H*hd) f32 views with unit last stride -> (B, Lq, H*hd) f32.
+    head_dim % 8 == 0 (<= 128), Lk <= 2048; bias as in attention()."""
+    _cuda(q, k, v, bias)
+    _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention_f32: operands must be (B, L, H*hd)")
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    _need(D % n_heads == 0 and k.shape == (B, Lk, D) and v.shape == (B, Lk, D), "attention_f32: shape mismatch")
+    for t in (q, k, v):
+        _need(t.dtype == torch.float32 and t.stride(2) == 1, "attention_f32: f32 operands with unit last stride")
+    out = torch.empty((B, Lq, D), dtype=torch.float32, device=q.device)
+    sb = sh = sq = 0
+    if bias is not None:
+        _need(bias.dim() == 4 and bias.dtype == torch.float32 and bias.shape[2:] == (Lq, Lk) and bias.stride(3) == 1
+              and bias.shape[0] in (1, B) and bias.shape[1] in (1, n_heads), "attention_f32: bias must be f32 (1|B, 1|H, Lq, Lk)")
+        sb = 0 if bias.shape[0] == 1 else bias.stride(0)
+        sh = 0 if bias.shape[1] == 1 else bias.stride(1)
+        sq = bias.stride(2)
+    rc = _launch("attention_f32", 4.0 * B * n_heads * Lq * Lk * (D // n_heads), lambda: lib().pm_attention_generic_f32(
+        q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1), v.data_ptr(), v.stride(0), v.stride(1),
+        out.data_ptr(), out.stride(0), out.stride(1), B, n_heads, Lq, Lk, D // n_heads, int(causal),
+        bias.data_ptr() if bias is not None else None, sb, sh, sq, _stream()))
+    check(rc, f"pm_attention_generic_f32(B={B}, H={n_heads}, Lq={Lq}, Lk={Lk}, hd={D // n_heads})")
+    return out
+
+
 def layernorm(x: Tensor, gamma: Tensor | None, beta: Tensor | None, eps: float, out_dtype: torch.dtype | None = None,
               act: str = "none", resid: Tensor | None = None) -> Tensor:
     """Row-wise LayerNorm of x (M, d) (bf16 | f32) with f32 gamma / beta (both None = no affine), optionally followed by
@@ -492,7 +548,7 @@ def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor | None, pos0: int = 0,
     tokens = tokens.contiguous()
     B, L = tokens.shape
     V, d = emb.shape
-    _need(emb.dtype == torch.bfloat16 and emb.is_contiguous(), "embed_tokens: emb bf16 (V, d)")
+    _need(emb.dtype in (torch.bfloat16, torch.float32) and emb.is_contiguous(), "embed_tokens: emb bf16 or f32 (V, d)")
     # nn.Embedding raises on an id outside [0, V) (whisper.py:48); the kernel clamps so that a bad id cannot fault, so
     # the range is checked here (one min / max read-back; skipped inside a graph capture, where the caller has
     # validated the example inputs eagerly during the warm-up pass)
@@ -503,6 +559,12 @@ def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor | None, pos0: int = 0,
     if pos is not None:
         _need(pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == d and pos.shape[0] >= pos0 + L,
               f"embed_tokens: need {pos0 + L} position rows, have {pos.shape[0]}")
+    if emb.dtype == torch.float32:  # fp32 table -> fp32 rows
+        out = torch.empty((B, L, d), dtype=torch.float32, device=emb.device)
+        rc = lib().pm_embed_tokens_f32(tokens.data_ptr(), emb.data_ptr(), pos.data_ptr() if pos is not None else None, out.data_ptr(),
+                                       B, L, pos0, d, V, _stream())
+        check(rc, f"pm_embed_tokens_f32(B={B}, L={L}, d={d})")
+        return out
     out = torch.empty((B, L, d), dtype=out_dtype, device=emb.device)
     rc = lib().pm_embed_tokens(tokens.data_ptr(), emb.data_ptr(), pos.data_ptr() if pos is not None else None, out.data_ptr(), _dt(out), B, L, pos0, d, V,
                                _stream())

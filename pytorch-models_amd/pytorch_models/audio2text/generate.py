@@ -373,3 +373,78 @@ def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: boo
     toks = st.run(graph)
     st.check()
     return (toks, st.margins) if margins else toks
+
+
+@torch.no_grad()
+def greedy_exact(dec, memory: Tensor | None, prompt: Tensor, n_new: int, *, margins: bool = False):
+    """KV-cached greedy decoding in fp32 END TO END for a decoder whose parameters are fp32: fp32 weights, fp32 activations,
+    fp32 self and cross K/V (nothing rounded to bf16 anywhere), one token per step through pm_linear_f32 /
+    pm_attention_generic_f32 / pm_layernorm.  This is the path whose ids are compared bit for bit with the reference's fp32
+    full-prefix loop (text/generator.py:23-35 semantics; tests/golden/whisper.npz greedy_*_224): same algebra as the
+    reference, cached instead of recomputed (the single-token step attends WITHOUT a causal flag: SURVEY.md F3).
+    ~14 eager launches per layer and step - a reference-accuracy mode, not the throughput path (that is GreedyDecoder on a
+    bf16 model).  Returns tokens (B, P + n_new) [and the top-1 minus top-2 logit of every generated position]."""
+    from ..transformer import MHA
+
+    E = dec.token_embs.weight
+    if E.dtype != torch.float32 or not E.is_cuda:
+        raise NotImplementedError("greedy_exact: fp32 parameters on a HIP device (bf16 models: GreedyDecoder, or Whisper.generate(exact=True))")
+    B, P = prompt.shape
+    V, d = E.shape
+    Ttot = P + n_new
+    if Ttot > dec.pos_embs.shape[0]:
+        raise ValueError(f"greedy decode: {Ttot} positions > max_seq_len {dec.pos_embs.shape[0]}")
+    dev = E.device
+    prompt = prompt.to(dev)
+    tokens = torch.zeros(B, Ttot, dtype=torch.int64, device=dev)
+    tokens[:, :P] = prompt
+    marg = torch.zeros(B, Ttot, dtype=torch.float32, device=dev) if margins else None
+    pos = dec.pos_embs.float()
+    layers = list(dec.layers)
+    for layer in layers:
+        if not layer.pre_norm or type(layer.sa) is not MHA:
+            raise NotImplementedError("greedy_exact: plain pre-norm layers only")
+    cross, caches = [], []
+    for layer in layers:
+        inner = layer.sa.n_heads * layer.sa.head_dim
+        caches.append((torch.empty(B, Ttot, inner, dtype=torch.float32, device=dev), torch.empty(B, Ttot, inner, dtype=torch.float32, device=dev)))
+        if layer.ca is not None:
+            if memory is None:
+                raise ValueError("greedy_exact: cross-attention layers need a memory")
+            w, b = layer.ca._pack32("kv")
+            mem = memory.float()
+            ci = layer.ca.n_heads * layer.ca.head_dim
+            kv = ops.linear_f32(mem.reshape(-1, mem.shape[-1]), w, b).view(B, mem.shape[1], 2 * ci)
+            cross.append((kv[..., :ci], kv[..., ci:]))
+        else:
+            cross.append(None)
+    for t in range(Ttot - 1):
+        x = ops.embed_tokens(tokens[:, t : t + 1], E, pos, pos0=t).view(B, d)  # f32 rows
+        for layer, (kc, vc), xkv in zip(layers, caches, cross):
+            sa = layer.sa
+            inner = sa.n_heads * sa.head_dim
+            w, b = sa._pack32("qkv")
+            qkv = ops.linear_f32(layer.sa_norm(x), w, b)
+            kc[:, t] = qkv[:, inner : 2 * inner]
+            vc[:, t] = qkv[:, 2 * inner :]
+            a = ops.attention_f32(qkv[:, :inner].unsqueeze(1), kc[:, : t + 1], vc[:, : t + 1], sa.n_heads)
+            x = ops.linear_f32(a.view(B, inner), sa.out_proj.weight, sa.out_proj.bias, resid=x)
+            if xkv is not None:
+                ca = layer.ca
+                q = ops.linear_f32(layer.ca_norm(x), ca.q_proj.weight, ca.q_proj.bias)
+                a = ops.attention_f32(q.unsqueeze(1), xkv[0], xkv[1], ca.n_heads)
+                x = ops.linear_f32(a.view(B, -1), ca.out_proj.weight, ca.out_proj.bias, resid=x)
+            mlp = layer.mlp
+            h = ops.linear_f32(layer.mlp_norm(x), mlp.linear1.weight, mlp.linear1.bias, act=mlp.act_name)
+            x = ops.linear_f32(h, mlp.linear2.weight, mlp.linear2.bias, resid=x)
+        logits = ops.linear_f32(dec.norm(x) if getattr(dec, "norm", None) is not None else x, E)  # (B, V) f32
+        if t + 1 < P:
+            tokens[:, t + 1] = prompt[:, t + 1]
+        else:
+            if margins:
+                top2 = logits.topk(2, -1)
+                marg[:, t + 1] = top2.values[:, 0] - top2.values[:, 1]
+                tokens[:, t + 1] = top2.indices[:, 0]
+            else:
+                tokens[:, t + 1] = logits.argmax(-1)
+    return (tokens, marg) if margins else tokens

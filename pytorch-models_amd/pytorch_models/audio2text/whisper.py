@@ -53,7 +53,9 @@ class WhisperEncoder(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         """(B, n_mels, T) -> (B, T // 2, d): conv stem (both convs as MFMA GEMMs with fused GELU, the second
         also adding pos_embs in its epilogue), Encoder, LayerNorm."""
-        w1, b1, w2, b2 = self._stem_weights()  # bf16 copies whatever the parameters' dtype
+        if self.stem[0].weight.dtype == torch.float32:
+            return self._forward_f32(x)
+        w1, b1, w2, b2 = self._stem_weights()
         B, _, T = x.shape
         d = w2.shape[0]
         y1 = ops.whisper_stem1(x.float().contiguous(), w1, b1)  # (B, T + 2, d) bf16, rows 0 and T + 1 zero
@@ -63,6 +65,26 @@ class WhisperEncoder(nn.Module):
         y2 = ops.linear_strided(y1, M=B * L, K=3 * d, row_stride=2 * d, rows_per_batch=L, batch_stride=(T + 2) * d,
                                 w=w2, bias=b2, act="gelu", resid=pos, resid_period=L)
         return self.norm(self.layers(y2.view(B, L, d)), self.stem[0].weight.dtype)  # fp32 model -> fp32 memory
+
+
+def _encoder_forward_f32(self: WhisperEncoder, x: Tensor) -> Tensor:
+    """fp32 parameters: both convolutions as fp32 GEMMs over windows (a window view + one contiguous copy each is layout,
+    the arithmetic is pm_linear_f32 with GELU and, for the second, + pos_embs in its epilogue), fp32 Encoder, fp32 LayerNorm."""
+    c1, c2 = self.stem[0], self.stem[2]
+    B, C, T = x.shape
+    d = c1.weight.shape[0]
+    xp = torch.nn.functional.pad(x.float(), (1, 1))
+    cols = xp.unfold(2, 3, 1).permute(0, 2, 1, 3).reshape(B * T, C * 3)  # (B T, C * 3): K order (channel, tap) = weight.view(d, -1)
+    y1 = ops.linear_f32(cols, c1.weight.view(d, C * 3), c1.bias, act="gelu").view(B, T, d)
+    L = (T - 1) // 2 + 1
+    yp = torch.nn.functional.pad(y1, (0, 0, 1, 1))
+    cols = yp.unfold(1, 3, 2).reshape(B * L, d * 3)  # window dim last: (B, L, d, 3) -> K order (channel, tap)
+    pos = self.pos_embs.float()[:L].contiguous()
+    y2 = ops.linear_f32(cols, c2.weight.view(d, d * 3), c2.bias, act="gelu", resid=pos, resid_period=L)
+    return self.norm(self.layers(y2.view(B, L, d)))
+
+
+WhisperEncoder._forward_f32 = _encoder_forward_f32
 
 
 class WhisperDecoder(nn.Module):
@@ -77,6 +99,10 @@ class WhisperDecoder(nn.Module):
 
     def forward(self, x: Tensor, memory: Tensor) -> Tensor:
         """tokens (B, L) int64, memory (B, S, d) -> logits (B, L, V) (tied embeddings), teacher-forced."""
+        if self.token_embs.weight.dtype == torch.float32:  # fp32 parameters: fp32 throughout
+            E = self.token_embs.weight
+            h = self.norm(self.layers(ops.embed_tokens(x, E, self.pos_embs), memory.float()))
+            return ops.linear_f32(h.view(-1, h.shape[-1]), E).view(*x.shape, E.shape[0])
         E = _wb(self.token_embs, "E", self.token_embs.weight)
         h = ops.embed_tokens(x, E, _f32(self, "pos", self.pos_embs))  # (B, L, d) bf16
         h = self.norm(self.layers(h, memory))
@@ -88,8 +114,12 @@ class WhisperDecoder(nn.Module):
         """Batched greedy decoding with a KV cache: (B, P) int64 prompt -> (B, P + max_new_tokens) ids.  ``rules``: a
         generate.WhisperRules (token suppression, timestamp pairing / monotonicity) applied to the logits on the device;
         ``path``: "persistent" / "launches" / "auto" (generate.GreedyDecoder)."""
-        from .generate import greedy_decode
+        from .generate import greedy_decode, greedy_exact
 
+        if self.token_embs.weight.dtype == torch.float32:  # fp32 parameters: the fp32 end-to-end loop (no bf16 storage points)
+            if rules is not None:
+                raise NotImplementedError("WhisperDecoder.generate: the decoding rules run on the bf16 model's step kernels")
+            return greedy_exact(self, memory, prompt, max_new_tokens)
         return greedy_decode(self, memory, prompt, max_new_tokens, graph=graph, rules=rules, path=path)
 
 
@@ -107,9 +137,29 @@ class Whisper(nn.Module):
         return self.decoder(targets, self.encoder(x))
 
     @torch.no_grad()
-    def generate(self, x: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, rules=None, path: str = "auto") -> Tensor:
-        """log-mel (B, n_mels, T) + prompt ids (B, P) -> greedy ids (B, P + max_new_tokens)."""
+    def generate(self, x: Tensor, prompt: Tensor, max_new_tokens: int, *, graph: bool = True, rules=None, path: str = "auto",
+                 exact: bool = False) -> Tensor:
+        """log-mel (B, n_mels, T) + prompt ids (B, P) -> greedy ids (B, P + max_new_tokens).
+        ``exact=True`` (bf16 model): the whole pipeline - encoder, cross K/V, decoder, caches - in fp32 on an fp32 copy of
+        this model's (bf16-valued) weights: the ids are those of the reference's fp32 forward on the same weights, bit for
+        bit (tests/test_hip_exact.py); costs ~10x the bf16 encoder and an eager fp32 step loop.  A model whose
+        parameters are fp32 always decodes this way."""
+        if exact and self.decoder.token_embs.weight.dtype != torch.float32:
+            return self.exact_copy().generate(x, prompt, max_new_tokens)
         return self.decoder.generate(self.encoder(x), prompt, max_new_tokens, graph=graph, rules=rules, path=path)
+
+    def exact_copy(self) -> "Whisper":
+        """fp32 twin of this model (same values: bf16 -> fp32 is exact), rebuilt when a parameter changes."""
+        import copy
+
+        params = list(self.parameters()) + list(self.buffers())
+        def build():
+            twin = copy.deepcopy(self).float()
+            for m in twin.modules():  # the twin derives its own packed / re-typed weights
+                m.__dict__.pop("_pm_derived", None)
+            return twin
+
+        return derived(self, "exact32", params, build)
 
     def load_openai_state_dict(self, state_dict) -> None:
         """OpenAI ``model_state_dict`` (e.g. ``torch.load(path, weights_only=True)["model_state_dict"]``)."""

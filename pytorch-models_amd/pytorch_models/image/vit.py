@@ -76,7 +76,9 @@ class ViT(nn.Module):
 
     def tokens(self, imgs: Tensor) -> Tensor:
         """(N, 3, H, W) f32 -> (N, L [+1], d) bf16: patch projection + pe (+ cls) in one kernel."""
-        pw = _wb(self.patch_embed, "w", self.patch_embed.weight)  # an fp32 model runs through a cached bf16 copy
+        if self.patch_embed.weight.dtype == torch.float32:
+            return self._tokens_f32(imgs)
+        pw = self.patch_embed.weight
         if pw.shape[2] == 16:
             w2d = pw.view(pw.shape[0], -1)
         else:  # other patch sizes: K = 3*P*P zero-padded to a multiple of 64 (derived copy)
@@ -90,6 +92,22 @@ class ViT(nn.Module):
         cls = None if self.cls_token is None else _f32(self, "cls", self.cls_token).view(-1)
         return ops.vit_tokens(imgs.float().contiguous(), w2d, _f32(self, "pb", self.patch_embed.bias),
                               _f32(self, "pe", self.pe).view(-1, pw.shape[0]), cls, pw.shape[2])
+
+    def _tokens_f32(self, imgs: Tensor) -> Tensor:
+        """fp32 parameters: the patch projection as an fp32 GEMM over patch windows (K order (channel, row, column) = the
+        Conv2d weight flattened), + pe in its epilogue; the cls row is prepended (broadcast over the batch: SURVEY F1)."""
+        w = self.patch_embed.weight
+        d, _, P, _ = w.shape
+        N, _, H, W = imgs.shape
+        gh, gw = H // P, W // P
+        cols = imgs.float().unfold(2, P, P).unfold(3, P, P).permute(0, 2, 3, 1, 4, 5).reshape(N * gh * gw, 3 * P * P)
+        pe = self.pe.float().view(-1, d)
+        if pe.shape[0] != gh * gw:
+            raise ValueError(f"ViT: pe holds {pe.shape[0]} positions, the image has {gh * gw} patches; call resize_pe first")
+        y = ops.linear_f32(cols, w.view(d, -1), self.patch_embed.bias, resid=pe.contiguous(), resid_period=gh * gw).view(N, gh * gw, d)
+        if self.cls_token is not None:
+            y = torch.cat([self.cls_token.float().expand(N, 1, d), y], 1)
+        return y
 
     def forward(self, imgs: Tensor) -> Tensor:
         out = self.layers(self.tokens(imgs))

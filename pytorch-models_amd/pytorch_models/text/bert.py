@@ -24,11 +24,11 @@ class BERT(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         """token ids (..., L) int64 -> hidden states (..., L, d) bf16 (bert.py:35-40)."""
-        E = _wb(self.token_embs, "E", self.token_embs.weight)
+        E = self.token_embs.weight  # fp32 table -> fp32 rows (and fp32 blocks behind them), bf16 -> bf16
         lead = x.shape
         h = ops.embed_tokens(x.reshape(-1, lead[-1]), E, _f32(self, "pos", self.pos_embs))
         h = self.layers(self.norm(h))
-        return h.view(*lead, h.shape[-1]).to(self.token_embs.weight.dtype)  # fp32 model -> fp32 hidden states
+        return h.view(*lead, h.shape[-1])
 
     @staticmethod
     def from_config(config: dict, **kwargs) -> "BERT":

@@ -16,9 +16,15 @@ _SIZES = {"gpt2": (12, 768), "gpt2-medium": (24, 1024), "gpt2-large": (36, 1280)
 
 
 def _lm_forward(m, tokens: Tensor, final_norm) -> Tensor:
-    E = _wb(m.token_embs, "E", m.token_embs.weight)  # an fp32 model runs through a cached bf16 copy of its weights
     lead = tokens.shape
     tok2 = tokens.reshape(-1, lead[-1])  # the reference also accepts an unbatched (L,) sequence (generator.py:25)
+    if m.token_embs.weight.dtype == torch.float32:  # fp32 parameters: fp32 rows, fp32 blocks, fp32 logits
+        E = m.token_embs.weight
+        h = m.layers(ops.embed_tokens(tok2, E, m.pos_embs))
+        if final_norm is not None:
+            h = final_norm(h)
+        return ops.linear_f32(h.view(-1, h.shape[-1]), E).view(*lead, E.shape[0])
+    E = m.token_embs.weight
     h = ops.embed_tokens(tok2, E, _f32(m, "pos", m.pos_embs))
     h = m.layers(h)
     if final_norm is not None:
@@ -47,8 +53,10 @@ class GPT2(nn.Module):
                  path: str = "auto") -> Tensor:
         """Batched decoding with a KV cache: (B, P) int64 prompt -> (B, P + max_new_tokens) ids; greedy (topk = 1) or
         top-k sampling on the device (softmax over the k largest logits; the same seed gives the same ids)."""
-        from ..audio2text.generate import greedy_decode
+        from ..audio2text.generate import greedy_decode, greedy_exact
 
+        if self.token_embs.weight.dtype == torch.float32 and topk == 1:  # fp32 parameters: fp32 end to end
+            return greedy_exact(self, None, prompt, max_new_tokens)
         return greedy_decode(self, None, prompt, max_new_tokens, graph=graph, topk=topk, seed=seed, path=path)
 
     @staticmethod

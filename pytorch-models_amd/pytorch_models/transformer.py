@@ -13,10 +13,12 @@ forward is a short sequence of hand-written gfx950 kernels reached through the C
     linear2 + residual   -> pm_linear_bf16 with the residual add in its epilogue
 
 There is no CPU or eager fallback: tensors must live on a HIP device; anything the kernels do not cover raises.
-The kernels compute in bf16 with fp32 accumulation.  ``model.to(torch.bfloat16)`` is the native form (bf16 activations
-end to end).  A model left in the reference's default fp32 still runs: its weights are used through cached bf16 copies,
-fp32 inputs are rounded to bf16 on the way in and every module returns the dtype it was given (fp32 residual stream) -
-same kernels, same bf16 tensor-core arithmetic, fp32 at the interface.
+A module computes in the dtype of its parameters:
+  * bf16 parameters (``model.to(torch.bfloat16)``, the throughput form): bf16 activations end to end, bf16 MFMA with fp32
+    accumulation, fp32 LayerNorm / softmax statistics;
+  * fp32 parameters (the reference's default): fp32 activations end to end on the exact-fp32 MFMA (pm_linear_f32,
+    pm_attention_generic_f32, fp32 LayerNorm) - the reference's own tolerances hold (2e-5 / 5e-5:
+    tests/test_hip_fp32_models.py) at roughly a tenth of the bf16 path's speed.  Nothing is silently rounded to bf16.
 """
 from __future__ import annotations
 
@@ -61,8 +63,12 @@ def _f32(module: nn.Module, key: str, t: Tensor | None) -> Tensor | None:
 _FLOATS = (torch.bfloat16, torch.float32)
 
 
+def _is32(p: Tensor) -> bool:
+    return p.dtype == torch.float32
+
+
 def _require_bf16(x: Tensor, w: Tensor, who: str) -> None:
-    """Device and dtype gate of every block: HIP tensors, bf16 or fp32 (fp32 is computed through bf16, see above)."""
+    """Device and dtype gate of every block: HIP tensors, bf16 or fp32 (each computed in its own dtype, see above)."""
     if not x.is_cuda or not w.is_cuda:
         raise RuntimeError(
             f"{who}: the MI355X build of pytorch_models runs on HIP devices only (input on {x.device}, weights on "
@@ -103,6 +109,9 @@ class Linear(nn.Linear):
 
     def forward(self, x: Tensor) -> Tensor:
         _require_bf16(x, self.weight, "Linear")
+        if _is32(self.weight):  # fp32 parameters: fp32 arithmetic
+            y = ops.linear_f32(x.float().reshape(-1, x.shape[-1]), self.weight, self.bias)
+            return y.view(*x.shape[:-1], self.out_features)
         y = ops.linear(_xb(x).reshape(-1, x.shape[-1]), _wb(self, "w", self.weight), _f32(self, "b", self.bias), out_dtype=x.dtype)
         return y.view(*x.shape[:-1], self.out_features)
 
@@ -145,6 +154,18 @@ class MHA(nn.Module):
 
         return derived(self, "pack_" + names, params, build)
 
+    def _pack32(self, names: str):
+        """fp32 modules: the concatenated fp32 weight / bias of the named projections."""
+        mods = [getattr(self, f"{n}_proj") for n in names]
+        params = [m.weight for m in mods] + [m.bias for m in mods]
+
+        def build():
+            w = torch.cat([m.weight.detach().float() for m in mods], 0).contiguous()
+            b = None if mods[0].bias is None else torch.cat([m.bias.detach().float() for m in mods], 0).contiguous()
+            return w, b
+
+        return derived(self, "pack32_" + names, params, build)
+
     def _pack_ln(self, norm: "LayerNorm"):
         """q/k/v projection with ``norm`` folded in: (w' = bf16(gamma (.) w), s[n] = sum_k w'[n][k],
         c[n] = b[n] + sum_k beta[k] w[n][k]) so that proj(norm(x)) = rstd * (x w'^T - mean * s) + c."""
@@ -170,6 +191,8 @@ class MHA(nn.Module):
             raise NotImplementedError("MHA: inference only (attention dropout is not implemented)")
         H, inner = self.n_heads, self.n_heads * self.head_dim
         Lq = q.shape[-2]
+        if _is32(self.q_proj.weight):
+            return self._attend_f32(q, k, v, attn_bias, causal, residual)
         io_dtype = q.dtype
         q = _xb(q)
         k = None if k is None else _xb(k)
@@ -194,27 +217,65 @@ class MHA(nn.Module):
             qh = qh.expand(*lead, Lq, inner).reshape(-1, Lq, inner)
             kh = kh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
             vh = vh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
-        bias4 = None
-        if attn_bias is not None:  # additive float bias or boolean keep-mask, broadcastable to (*lead, H, Lq, Lk)
-            ab = attn_bias
-            if ab.dtype == torch.bool:
-                ab = torch.zeros_like(ab, dtype=torch.float32).masked_fill_(~ab, float("-inf"))
-            ab = ab.float()
-            while ab.dim() < 4:
-                ab = ab.unsqueeze(0)
-            if ab.dim() > 4:  # several leading batch dims: flatten them like q
-                ab = ab.expand(*lead, *ab.shape[-3:]).reshape(-1, *ab.shape[-3:])
-            Lk_ = kh.shape[1]
-            bias4 = ab.expand(ab.shape[0], ab.shape[1], Lq, Lk_)
-            # the kernels walk the bias by (batch, head, query) strides with unit key stride; batch / head strides may be 0
-            # (broadcast), a query stride of 0 - a key-padding mask (B, 1, 1, Lk) - is materialised (Lq rows per mask)
-            if bias4.stride(3) != 1 or (Lq > 1 and bias4.stride(2) == 0):
-                bias4 = bias4.contiguous()
+        bias4 = None if attn_bias is None else _bias4(attn_bias, lead, Lq, kh.shape[1])
         o = ops.attention(qh, kh, vh, H, causal, bias4)
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])
         y = ops.linear(o.view(-1, inner), _wb(self.out_proj, "w", self.out_proj.weight), _f32(self.out_proj, "b", self.out_proj.bias),
                        resid=res2, out_dtype=io_dtype)
         return y.view(*lead, Lq, y.shape[-1])
+
+
+def _bias4(attn_bias: Tensor, lead, Lq: int, Lk: int) -> Tensor:
+    """additive float bias or boolean keep-mask, broadcastable to (*lead, H, Lq, Lk) -> f32 (b, h, Lq, Lk) with unit key
+    stride and a non-zero query stride (batch / head strides may be 0)."""
+    ab = attn_bias
+    if ab.dtype == torch.bool:
+        ab = torch.zeros_like(ab, dtype=torch.float32).masked_fill_(~ab, float("-inf"))
+    ab = ab.float()
+    while ab.dim() < 4:
+        ab = ab.unsqueeze(0)
+    if ab.dim() > 4:  # several leading batch dims: flatten them like q
+        ab = ab.expand(*lead, *ab.shape[-3:]).reshape(-1, *ab.shape[-3:])
+    bias4 = ab.expand(ab.shape[0], ab.shape[1], Lq, Lk)
+    if bias4.stride(3) != 1 or (Lq > 1 and bias4.stride(2) == 0):
+        bias4 = bias4.contiguous()
+    return bias4
+
+
+def _attend_f32(self: MHA, q, k, v, attn_bias, causal, residual):
+    """MHA.attend for fp32 parameters: the same call forms, fp32 activations and arithmetic throughout."""
+    H, inner = self.n_heads, self.n_heads * self.head_dim
+    Lq = q.shape[-2]
+    q = q.float()
+    k = None if k is None else k.float()
+    v = None if v is None else v.float()
+    if k is None and v is None:
+        lead = q.shape[:-2]
+        w, b = self._pack32("qkv")
+        qkv = ops.linear_f32(q.reshape(-1, q.shape[-1]), w, b).view(-1, Lq, 3 * inner)
+        qh, kh, vh = qkv[..., :inner], qkv[..., inner : 2 * inner], qkv[..., 2 * inner :]
+    else:
+        k = q if k is None else k
+        Lk = k.shape[-2]
+        lead = torch.broadcast_shapes(q.shape[:-2], k.shape[:-2])
+        qh = self.q_proj(q)
+        if v is None or v is k:
+            w, b = self._pack32("kv")
+            kv = ops.linear_f32(k.reshape(-1, k.shape[-1]), w, b).view(*k.shape[:-1], 2 * inner)
+            kh, vh = kv[..., :inner], kv[..., inner:]
+        else:
+            kh, vh = self.k_proj(k), self.v_proj(v)
+        qh = qh.expand(*lead, Lq, inner).reshape(-1, Lq, inner)
+        kh = kh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
+        vh = vh.expand(*lead, Lk, inner).reshape(-1, Lk, inner)
+    bias4 = None if attn_bias is None else _bias4(attn_bias, lead, Lq, kh.shape[1])
+    o = ops.attention_f32(qh, kh, vh, H, causal, bias4)
+    res2 = None if residual is None else residual.float().reshape(-1, residual.shape[-1])
+    y = ops.linear_f32(o.view(-1, inner), self.out_proj.weight, self.out_proj.bias, resid=res2)
+    return y.view(*lead, Lq, y.shape[-1])
+
+
+MHA._attend_f32 = _attend_f32
 
 
 def _fold_ln(w: Tensor, b: Tensor | None, norm: "LayerNorm"):
@@ -245,6 +306,10 @@ class MLP(nn.Module):
         _require_bf16(x, self.linear1.weight, "MLP")
         if self.training and self.dropout.p > 0.0:
             raise NotImplementedError("MLP: inference only (dropout is not implemented)")
+        if _is32(self.linear1.weight):
+            h = ops.linear_f32(x.float().reshape(-1, x.shape[-1]), self.linear1.weight, self.linear1.bias, act=self.act_name)
+            res2 = None if residual is None else residual.float().reshape(-1, residual.shape[-1])
+            return ops.linear_f32(h, self.linear2.weight, self.linear2.bias, resid=res2).view(*x.shape)
         x2 = _xb(x).reshape(-1, x.shape[-1])
         h = ops.linear(x2, _wb(self.linear1, "w", self.linear1.weight), _f32(self.linear1, "b", self.linear1.bias), act=self.act_name)
         res2 = None if residual is None else residual.reshape(-1, residual.shape[-1])

@@ -240,6 +240,31 @@ def g_whisper():
         out[f"greedy_{tag}_memory_digest"] = digest(memory)
         out[f"greedy_{tag}_memory_slice"] = memory[:, ::100, ::32]
         print(tag, "layers", len(w.encoder.layers), "min margin", float(torch.stack(margins, 1).min()))
+
+    # the full-length run of BASELINE configs[2]'s decode (prompt 4, 224 new tokens), B = 2, by the reference's full-prefix
+    # loop: once on the reference's plain fp32 weights ("f"), once on bf16-representable weights ("r": what a bf16 model on
+    # the GPU holds, so that the fp32 reference forward and the exact mode of the HIP path see the SAME weights)
+    from synthweights import bf16_round_
+
+    for tag, seed in (("tiny", 55), ("base", 56)):
+        for kind in ("f", "r"):
+            w = Whisper.from_openai(tag).eval()
+            fill_module(w, seed)
+            if kind == "r":
+                bf16_round_(w)
+            wave = synth_input(f"w_wave_{tag}", (2, 480000), seed, scale=0.1)
+            memory = w.encoder(WhisperPreprocessor(tag)(wave))
+            toks = synth_tokens(f"w_prompt_{tag}", (2, 4), 51865, seed)
+            margins = []
+            for _ in range(224):
+                last = w.decoder(toks, memory)[:, -1]
+                top2 = last.topk(2, -1)
+                margins.append(top2.values[:, 0] - top2.values[:, 1])
+                toks = torch.cat([toks, top2.indices[:, :1]], 1)
+            out[f"greedy224{kind}_{tag}_tokens"] = toks
+            out[f"greedy224{kind}_{tag}_margins"] = torch.stack(margins, 1)
+            out[f"greedy224{kind}_{tag}_memory_digest"] = digest(memory)
+            print(tag, kind, "224 tokens: min margin", float(torch.stack(margins, 1).min()))
     save("whisper", {}, **out)
 
 

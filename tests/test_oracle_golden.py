@@ -11,7 +11,7 @@ from oracle import ref_spectrogram as RS
 from oracle import ref_transformer as RT
 from oracle import ref_vit as RV
 from oracle import ref_whisper as RW
-from synthweights import fill_module, synth_input, synth_tokens
+from synthweights import bf16_round_, fill_module, synth_input, synth_tokens
 
 torch.set_grad_enabled(False)
 TOL = dict(rtol=2e-5, atol=2e-5)
@@ -262,3 +262,25 @@ def test_whisper_greedy_ids(golden, tag, seed):
     torch.testing.assert_close(marg_c, margins, rtol=0, atol=2e-4)
     toks_r, _ = RW.greedy_recompute(sd, "decoder.", prompt, memory, 8)
     assert torch.equal(toks_r, want[:, :12])
+
+
+@pytest.mark.parametrize("tag,seed", [("tiny", 55), ("base", 56)])
+@pytest.mark.parametrize("kind", ["f", "r"])
+def test_greedy_ids_224_tokens_bit_exact(golden, tag, seed, kind):
+    """The full-length decode of BASELINE configs[2] (prompt 4, 224 new tokens; make_golden.py ran the reference's
+    full-prefix loop): the oracle's KV-cached loop gives the same ids bit for bit, on the reference's plain fp32 weights
+    ("f") and on bf16-representable weights ("r": the weights a bf16 model on the GPU holds)."""
+    from pytorch_models.audio2text import Whisper
+
+    g = golden("whisper")
+    m = Whisper.from_openai(tag)
+    fill_module(m, seed)
+    if kind == "r":
+        bf16_round_(m)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    wave = synth_input(f"w_wave_{tag}", (2, 480000), seed, scale=0.1)
+    memory = RW.encoder(sd, "encoder.", RS.whisper_log_mel(wave, 80, "rfft"))
+    prompt = synth_tokens(f"w_prompt_{tag}", (2, 4), 51865, seed)
+    toks, margins = RW.greedy_cached(sd, "decoder.", prompt, memory, 224)
+    assert torch.equal(toks, g[f"greedy224{kind}_{tag}_tokens"])
+    torch.testing.assert_close(margins, g[f"greedy224{kind}_{tag}_margins"], rtol=1e-3, atol=2e-5)
