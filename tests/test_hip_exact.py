@@ -70,15 +70,30 @@ def test_blocks_at_the_reference_tolerance(golden):
     """Encoder / Decoder stacks with the reference's plain fp32 weights against blocks.npz (captured from the reference)."""
     from pytorch_models.transformer import Decoder, Encoder
 
+    from pytorch_models.transformer import DecoderLayer, EncoderLayer
+
     g = golden("blocks")
-    m = Encoder(3, 128, n_heads=4).cuda().eval()
-    fill_module(m, 13)
-    got = m(synth_input("enc3_x", (2, 9, 128), 13).cuda())
+    x, mem = synth_input("blk_x", (2, 10, 64), 1).cuda(), synth_input("blk_mem", (2, 7, 64), 1).cuda()
+    for pre in (True, False):
+        for eps in (1e-5, 1e-6):
+            m = EncoderLayer(64, pre_norm=pre, norm_eps=eps).cuda().eval()
+            fill_module(m, 11)
+            torch.testing.assert_close(m(x).cpu(), g[f"enc_pre{int(pre)}_eps{eps}"], **REF)
+            m = DecoderLayer(64, cross_attn=True, pre_norm=pre, norm_eps=eps).cuda().eval()
+            fill_module(m, 12)
+            torch.testing.assert_close(m(x, mem).cpu(), g[f"dec_pre{int(pre)}_eps{eps}"], **REF)
+    for act in ("gelu", "approximate_gelu", "relu", "silu"):
+        m = EncoderLayer(64, act=act).cuda().eval()
+        fill_module(m, 14)
+        torch.testing.assert_close(m(x).cpu(), g[f"enc_act_{act}"], **REF)
+    m = Encoder(3, 128, n_heads=2).cuda().eval()
+    fill_module(m, 15)
+    got = m(synth_input("blk_x128", (2, 9, 128), 1).cuda())
     assert got.dtype == torch.float32
     torch.testing.assert_close(got.cpu(), g["encoder3"], **REF)
-    m = Decoder(2, 128, n_heads=4, cross_attn=True).cuda().eval()
-    fill_module(m, 14)
-    got = m(synth_input("dec2_x", (2, 9, 128), 14).cuda(), synth_input("dec2_m", (2, 5, 128), 14).cuda())
+    m = Decoder(2, 128, cross_attn=True).cuda().eval()
+    fill_module(m, 16)
+    got = m(synth_input("blk_x128", (2, 9, 128), 1).cuda(), synth_input("blk_mem128", (2, 5, 128), 1).cuda())
     torch.testing.assert_close(got.cpu(), g["decoder2"], **REF)
 
 
