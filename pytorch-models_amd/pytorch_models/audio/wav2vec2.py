@@ -24,7 +24,7 @@ import torch
 from torch import Tensor, nn
 
 from .._hip import ops
-from ..transformer import Encoder, LayerNorm, Linear, _f32, derived
+from ..transformer import Encoder, LayerNorm, Linear, _f32, derived, require_bf16_params
 
 
 class LayerNorm1d(nn.LayerNorm):
@@ -166,6 +166,7 @@ class Wav2Vec2(nn.Module):
         return out.view(B, To, G * co)
 
     def _features(self, x: Tensor) -> Tensor:
+        require_bf16_params(self, type(self).__name__)
         return self.proj(self.feature_encoder.time_major(x))  # (B, T, d) bf16
 
     def forward(self, x: Tensor) -> Tensor:

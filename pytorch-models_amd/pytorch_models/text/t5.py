@@ -19,7 +19,7 @@ import torch
 from torch import Tensor, nn
 
 from .._hip import ops
-from ..transformer import MHA, Linear, _f32, _wb, derived
+from ..transformer import MHA, Linear, _f32, _wb, derived, require_bf16_params
 
 
 class LayerNorm(nn.Module):
@@ -123,6 +123,7 @@ class T5Encoder(nn.Module):
         self.out_drop = nn.Dropout(dropout)
 
     def forward(self, x: Tensor) -> Tensor:
+        require_bf16_params(self, "T5Encoder")
         bias = self.attn_bias(x.shape[-2], bidirection=True)
         for layer in self.layers:
             x = layer(x, attn_bias=bias)
@@ -139,6 +140,7 @@ class T5Decoder(nn.Module):
         self.out_drop = nn.Dropout(dropout)
 
     def forward(self, x: Tensor, memory: Tensor) -> Tensor:
+        require_bf16_params(self, "T5Decoder")
         bias = self.attn_bias(x.shape[-2], bidirection=False)  # + the causal mask, applied inside the attention kernel
         for layer in self.layers:
             x = layer(x, memory, attn_bias=bias, causal=True)

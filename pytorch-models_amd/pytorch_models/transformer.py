@@ -77,6 +77,16 @@ def _require_bf16(x: Tensor, w: Tensor, who: str) -> None:
         raise NotImplementedError(f"{who}: bf16 or fp32 only (weights {w.dtype}, input {x.dtype})")
 
 
+def require_bf16_params(module: nn.Module, who: str) -> None:
+    """Model families whose own kernels exist in bf16 only (the wav2vec2 stems / positional convolutions, T5's RMS norm,
+    GEGLU and bias gather): an fp32 instance is refused instead of being computed through bf16 copies."""
+    p = next(module.parameters(), None)
+    if p is not None and p.dtype != torch.bfloat16:
+        raise NotImplementedError(
+            f"{who}: bf16 parameters only on this build (got {p.dtype}); call model.to(torch.bfloat16).  The fp32-accurate path "
+            "covers the shared transformer blocks, ViT, Whisper, GPT / GPT-2 and BERT.")
+
+
 def _wb(module: nn.Module, key: str, p: Tensor) -> Tensor:
     """The parameter itself if it is bf16, else a cached bf16 copy (rebuilt when the parameter changes)."""
     if p.dtype == torch.bfloat16:

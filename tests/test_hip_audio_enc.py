@@ -188,16 +188,19 @@ def test_models_end_to_end(golden, name):
 
 
 def test_fp32_model_and_batch_invariance(golden):
-    """The reference's default fp32 module runs on the same kernels (fp32 out); clips of a batch do not interact."""
+    """An fp32 instance is refused loudly (this family's stem / positional-conv kernels exist in bf16 only: it is not run
+    through bf16 copies behind the caller's back); clips of a batch do not interact."""
     from pytorch_models.audio import Wav2Vec2
 
     g = golden("audio_enc")
     m = Wav2Vec2(2, 64)
     fill_module(m, 82)
-    m = m.cuda().eval()
     x = synth_input("w2v_x", (2, 6400), 81).cuda()
+    with pytest.raises(NotImplementedError, match="bf16 parameters only"):
+        m.cuda().eval()(x)
+    m = m.to(torch.bfloat16).cuda().eval()
     y = m(x)
-    assert y.dtype == torch.float32 and rel(y, g["w2v_d64"]) < 3e-2
+    assert y.dtype == torch.bfloat16 and rel(y, g["w2v_d64"]) < 3e-2
     assert torch.equal(m(x[1:]), y[1:])
 
 
@@ -234,7 +237,7 @@ def test_graphed_forward_replays_the_eager_launches():
 
 def test_no_projection_when_stem_width_equals_d_model_and_fp32_sew():
     """d_model = 512 = the stem's width: proj is the LayerNorm alone (wav2vec2.py:67-68), and the positional conv has 32
-    channels per group.  SEW left in fp32 (the reference's default) returns fp32 at the stem's frame rate."""
+    channels per group.  SEW left in fp32 is refused; in bf16 it returns the stem's frame rate."""
     from pytorch_models.audio import SEW, Wav2Vec2
 
     m, sd = prep(Wav2Vec2(1, 512), 87)
@@ -245,5 +248,7 @@ def test_no_projection_when_stem_width_equals_d_model_and_fp32_sew():
     s = SEW(2, 128)
     fill_module(s, 85)
     sd = {k: v.clone() for k, v in s.state_dict().items()}
-    ys = s.cuda().eval()(x.cuda())
-    assert ys.dtype == torch.float32 and ys.shape == (2, 19, 128) and rel(ys, RA.sew(sd, x)) < 3e-2
+    with pytest.raises(NotImplementedError, match="bf16 parameters only"):
+        s.cuda().eval()(x.cuda())
+    ys = s.to(torch.bfloat16).cuda().eval()(x.cuda())
+    assert ys.dtype == torch.bfloat16 and ys.shape == (2, 19, 128) and rel(ys, RA.sew(sd, x)) < 3e-2
