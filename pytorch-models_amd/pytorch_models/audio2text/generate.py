@@ -383,7 +383,8 @@ def greedy_exact(dec, memory: Tensor | None, prompt: Tensor, n_new: int, *, marg
     full-prefix loop (text/generator.py:23-35 semantics; tests/golden/whisper.npz greedy_*_224): same algebra as the
     reference, cached instead of recomputed (the single-token step attends WITHOUT a causal flag: SURVEY.md F3).
     ~14 eager launches per layer and step - a reference-accuracy mode, not the throughput path (that is GreedyDecoder on a
-    bf16 model).  Returns tokens (B, P + n_new) [and the top-1 minus top-2 logit of every generated position]."""
+    bf16 model).  It is also the KV-cached decode of what GreedyDecoder's step kernels do not cover: post-norm stacks (GPT)
+    and heads other than 64 wide / n_heads * head_dim != d_model (any head_dim % 8 == 0 up to 128).  Returns tokens (B, P + n_new) [and the top-1 minus top-2 logit of every generated position]."""
     from ..transformer import MHA
 
     E = dec.token_embs.weight
@@ -402,8 +403,8 @@ def greedy_exact(dec, memory: Tensor | None, prompt: Tensor, n_new: int, *, marg
     pos = dec.pos_embs.float()
     layers = list(dec.layers)
     for layer in layers:
-        if not layer.pre_norm or type(layer.sa) is not MHA:
-            raise NotImplementedError("greedy_exact: plain pre-norm layers only")
+        if type(layer.sa) is not MHA or layer.sa.head_dim % 8 or layer.sa.head_dim > 128:
+            raise NotImplementedError("greedy_exact: plain MHA layers with head_dim % 8 == 0 (<= 128)")
     cross, caches = [], []
     for layer in layers:
         inner = layer.sa.n_heads * layer.sa.head_dim
@@ -421,22 +422,30 @@ def greedy_exact(dec, memory: Tensor | None, prompt: Tensor, n_new: int, *, marg
     for t in range(Ttot - 1):
         x = ops.embed_tokens(tokens[:, t : t + 1], E, pos, pos0=t).view(B, d)  # f32 rows
         for layer, (kc, vc), xkv in zip(layers, caches, cross):
+            # pre-norm: x + f(norm(x)); post-norm (GPT, text/gpt.py:23): norm(x + f(x)) - transformer.py:96-105
+            pre = layer.pre_norm
             sa = layer.sa
             inner = sa.n_heads * sa.head_dim
             w, b = sa._pack32("qkv")
-            qkv = ops.linear_f32(layer.sa_norm(x), w, b)
+            qkv = ops.linear_f32(layer.sa_norm(x) if pre else x, w, b)
             kc[:, t] = qkv[:, inner : 2 * inner]
             vc[:, t] = qkv[:, 2 * inner :]
             a = ops.attention_f32(qkv[:, :inner].unsqueeze(1), kc[:, : t + 1], vc[:, : t + 1], sa.n_heads)
             x = ops.linear_f32(a.view(B, inner), sa.out_proj.weight, sa.out_proj.bias, resid=x)
+            if not pre:
+                x = layer.sa_norm(x)
             if xkv is not None:
                 ca = layer.ca
-                q = ops.linear_f32(layer.ca_norm(x), ca.q_proj.weight, ca.q_proj.bias)
+                q = ops.linear_f32(layer.ca_norm(x) if pre else x, ca.q_proj.weight, ca.q_proj.bias)
                 a = ops.attention_f32(q.unsqueeze(1), xkv[0], xkv[1], ca.n_heads)
                 x = ops.linear_f32(a.view(B, -1), ca.out_proj.weight, ca.out_proj.bias, resid=x)
+                if not pre:
+                    x = layer.ca_norm(x)
             mlp = layer.mlp
-            h = ops.linear_f32(layer.mlp_norm(x), mlp.linear1.weight, mlp.linear1.bias, act=mlp.act_name)
+            h = ops.linear_f32(layer.mlp_norm(x) if pre else x, mlp.linear1.weight, mlp.linear1.bias, act=mlp.act_name)
             x = ops.linear_f32(h, mlp.linear2.weight, mlp.linear2.bias, resid=x)
+            if not pre:
+                x = layer.mlp_norm(x)
         logits = ops.linear_f32(dec.norm(x) if getattr(dec, "norm", None) is not None else x, E)  # (B, V) f32
         if t + 1 < P:
             tokens[:, t + 1] = prompt[:, t + 1]

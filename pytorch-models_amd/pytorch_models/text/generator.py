@@ -25,12 +25,33 @@ class DecoderGenerator:
         device = p0.device
         tokens = list(tokens)
         n = len(tokens)
-        # the KV-cached step kernels stream bf16 weights: a model left in fp32 (the reference's default) takes the
-        # reference's own loop below - forward() on the whole prefix per token - instead of raising in the cached path
+        # KV-cached decoding: the graph-replayed step kernels for bf16 pre-norm stacks (GPT-2), the fp32 cached loop
+        # (generate.greedy_exact) for everything else the layer algebra covers - fp32 parameters, post-norm stacks (GPT) -
+        # instead of the reference's O(T^2) full-prefix loop, which remains for top-k sampling on those models
         kv_ok = p0.dtype == torch.bfloat16 and all(l.pre_norm for l in self.model.layers)
+        room = self.model.pos_embs.shape[0] - n
         if topk <= 64 and hasattr(self.model, "generate") and kv_ok:
-            room = self.model.pos_embs.shape[0] - n
             out = self.model.generate(torch.tensor([tokens], device=device), min(max_tokens, room), topk=topk, seed=seed)[0].tolist()
+            new = out[n:]
+            if eos_token_id is not None and eos_token_id in new:
+                new = new[: new.index(eos_token_id) + 1]
+            return tokens + new
+        if topk == 1 and hasattr(self.model, "token_embs") and hasattr(self.model, "pos_embs"):
+            from ..audio2text.generate import greedy_exact
+            from ..transformer import derived
+
+            m32 = self.model
+            if p0.dtype != torch.float32:  # fp32 twin of a bf16 post-norm model (same values), rebuilt when a parameter changes
+                import copy
+
+                def build():
+                    twin = copy.deepcopy(self.model).float()
+                    for mod in twin.modules():
+                        mod.__dict__.pop("_pm_derived", None)
+                    return twin
+
+                m32 = derived(self.model, "exact32", list(self.model.parameters()), build)
+            out = greedy_exact(m32, None, torch.tensor([tokens], device=device), min(max_tokens, room))[0].tolist()
             new = out[n:]
             if eos_token_id is not None and eos_token_id in new:
                 new = new[: new.index(eos_token_id) + 1]

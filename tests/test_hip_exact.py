@@ -174,3 +174,44 @@ def test_exact_mode_of_the_bf16_model_equals_the_reference_bit_for_bit(golden, t
         small = (g[f"greedy224r_{tag}_margins"][b] < 0.05).nonzero()
         upto = 4 + (int(small[0]) if len(small) else 224)
         assert p >= upto, (tag, b, p, upto)
+
+
+def test_cached_fp32_loop_covers_post_norm_and_other_head_shapes():
+    """generate.greedy_exact is also the KV-cached decode of what the bf16 step kernels do not cover (missing 6):
+    a post-norm stack (GPT, text/gpt.py:23) and heads with n_heads * head_dim != d_model.  Against the reference's own loop
+    - forward() on the whole prefix per token (text/generator.py:23-35) - in the same fp32 arithmetic: identical ids."""
+    from pytorch_models.text import GPT, DecoderGenerator
+
+    class Tok:
+        eos_token_id = None
+
+    m = GPT(n_layers=2, d_model=128).cuda().eval()  # post-norm, no final norm
+    fill_module(m, 61)
+    prompt = synth_tokens("gx_p", (7,), 40478, 61).tolist()
+    got = DecoderGenerator(m, Tok()).generate_ids(prompt, 12)
+    toks = list(prompt)
+    for _ in range(12):
+        toks.append(int(m(torch.tensor(toks, device="cuda"))[-1].argmax(-1)))
+    assert got == toks
+    mb = GPT(n_layers=2, d_model=128).eval()  # the bf16 model decodes through an fp32 twin of the same values
+    fill_module(mb, 61)
+    bf16_round_(mb)
+    want = DecoderGenerator(mb.cuda(), Tok()).generate_ids(prompt, 12)
+    assert DecoderGenerator(mb.to(torch.bfloat16), Tok()).generate_ids(prompt, 12) == want
+
+    # heads of 32 with n_heads * head_dim (64) != d_model (128), cross-attention, pre-norm
+    from pytorch_models.audio2text.generate import greedy_exact
+    from pytorch_models.audio2text.whisper import WhisperDecoder
+    from pytorch_models.transformer import Decoder
+
+    d = WhisperDecoder(300, 2, 128).eval()
+    d.layers = Decoder(2, 128, n_heads=2, head_dim=32, cross_attn=True)
+    d = d.cuda()
+    fill_module(d, 62)
+    mem = synth_input("gx_mem", (3, 21, 128), 62).cuda()
+    p = synth_tokens("gx_p2", (3, 2), 300, 62).cuda()
+    got = greedy_exact(d, mem, p, 9)
+    toks = p.clone()
+    for _ in range(9):
+        toks = torch.cat([toks, d(toks, mem)[:, -1].argmax(-1, keepdim=True)], 1)
+    assert torch.equal(got, toks)
