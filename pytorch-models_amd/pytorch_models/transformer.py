@@ -38,7 +38,8 @@ _ACTS = {
 
 
 def _sig(ts) -> tuple:
-    return tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ts if t is not None)
+    # (tensors created under torch.inference_mode() - e.g. the fp32 twin a generator builds - carry no version counter)
+    return tuple((t.data_ptr(), 0 if t.is_inference() else t._version, t.dtype, t.device) for t in ts if t is not None)
 
 
 def derived(module: nn.Module, key: str, params, build):
