@@ -267,9 +267,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
       }                                                                                                              \
     }                                                                                                                \
     char* xs_ = smem + pp_buf * STAGE_BYTES;                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16(X + xoff[i] + pp_kt * BK, xs_ + (wave * 32 + i * 8) * 128); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16_aux<PM_GLDS_X_AUX>(X + xoff[i] + pp_kt * BK, xs_ + (wave * 32 + i * 8) * 128); \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
-        glds16(W + woff[i] + pp_kt * BK, xs_ + LBM * 128 + (wave * 16 + i * 8) * 128);                                \
+        glds16_aux<PM_GLDS_W_AUX>(W + woff[i] + pp_kt * BK, xs_ + LBM * 128 + (wave * 16 + i * 8) * 128);                                \
     ++pp;                                                                                                            \
     pp_buf = pp_buf == 2 ? 0 : pp_buf + 1;                                                                           \
     if (++pp_kt == nk) { pp_kt = 0; ++pp_tile; }                                                                     \
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_persist_kernel(
 #ifdef PM_ABLATE_STORES  // experiment only
           asm volatile("" ::"v"(o));
 #else
-          if (ok) *(bf16x8*)(ybase + (int64_t)(i * 16 + p * 8) * ldy) = o;  // N % 8 == 0 on this path
+          if (ok) store_y((bf16x8*)(ybase + (int64_t)(i * 16 + p * 8) * ldy), o);  // N % 8 == 0 on this path
 #endif
         }
       }

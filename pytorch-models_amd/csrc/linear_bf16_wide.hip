@@ -31,7 +31,10 @@ constexpr int WRING = WBK == 32 ? 4 : 2;
 constexpr int WROWB = WBK * 2;          // bytes per LDS row
 constexpr int WPIECE_ROWS = 1024 / WROWB;  // rows per 1 KiB LDS-DMA piece: 16 or 8
 constexpr int WNPIECE = 32 / WPIECE_ROWS;  // pieces per operand and wave (32 rows each): 2 or 4
-constexpr int WGROUP_M = 4;
+#ifndef PM_WGROUP_M
+#define PM_WGROUP_M 4
+#endif
+constexpr int WGROUP_M = PM_WGROUP_M;
 // Priority: waves 4-7 (the younger wave of each SIMD pair, which loses every age-based arbitration and made waves 0-3
 // wait ~600-1200 cycles at each barrier) run at s_setprio 1 for the whole kernel; no per-step flips
 // (MI355X_MICROARCH.md, two waves per SIMD, item 4).  out_proj -4.5 %, fc2 -3 %, fc1 / QKV -1 %.  0 = the old flips.
@@ -99,9 +102,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
     }                                                                                                                \
     char* xs_ = smem + pp_buf * WSTAGE;                                                                              \
     _Pragma("unroll") for (int i = 0; i < WNPIECE; ++i)                                                              \
-        glds16(X + xoff[i] + pp_kt * WBK, xs_ + (wave * 32 + i * WPIECE_ROWS) * WROWB);                               \
+        glds16_aux<PM_GLDS_X_AUX>(X + xoff[i] + pp_kt * WBK, xs_ + (wave * 32 + i * WPIECE_ROWS) * WROWB);                               \
     _Pragma("unroll") for (int i = 0; i < WNPIECE; ++i)                                                              \
-        glds16(W + woff[i] + pp_kt * WBK, xs_ + WBM * WROWB + (wave * 32 + i * WPIECE_ROWS) * WROWB);                 \
+        glds16_aux<PM_GLDS_W_AUX>(W + woff[i] + pp_kt * WBK, xs_ + WBM * WROWB + (wave * 32 + i * WPIECE_ROWS) * WROWB);                 \
     ++pp;                                                                                                            \
     pp_buf = (pp_buf + 1) & (WRING - 1);                                                                             \
     if (++pp_kt == nk) { pp_kt = 0; ++pp_tile; }                                                                     \
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_wide_kernel(
             for (int r = 0; r < 4; ++r) { o[r] = (bf16)lo[r]; o[4 + r] = (bf16)hi[r]; }
           }
           if (i * 16 + p * 8 < mleft && n0 + hf * 64 + sch * 8 < N)  // N % 8 == 0 on this path
-            *(bf16x8*)(ybase + (int64_t)(i * 16 + p * 8) * ldy + hf * 64) = o;
+            store_y((bf16x8*)(ybase + (int64_t)(i * 16 + p * 8) * ldy + hf * 64), o);
         }
       }
     }
