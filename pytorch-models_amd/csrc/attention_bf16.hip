@@ -13,6 +13,8 @@
 //   O^T = V^T P^T : the S^T accumulator, converted to bf16 in place, IS the B operand (k = key); the
 //                   A operand V^T comes from the row-major V image through ds_read_b64_tr_b16.
 //                   O^T again has the query on the lane, so the online-softmax rescale is per lane.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -242,6 +244,206 @@ _Pragma("unroll")                                                               
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Short self-attention (Lq, Lk <= 256, no mask, no bias: ViT's 197 tokens).  At this length the tiled kernel above is
+// bound by what a CU can pull in (two workgroups per head each stage the head's whole K and V: 467 MB at C2 against
+// 309 MB read once, at the ~4.4 TB/s that 256 CUs ingest), not by its arithmetic.  So: ONE persistent workgroup per
+// CU walks (batch, head) pairs; 8 waves x 32 queries cover the head, its K and V land in LDS once (LDS-DMA, no
+// registers), double-buffered - the next head's 50 KB stream in while this one is computed - and a wave keeps ALL its
+// scores in registers (NB blocks of 32 keys x 16 values): the softmax is exact in one pass (no running max, no O
+// rescale), padding is per 32 keys (QK^T) and 16 keys (PV).  One barrier per head.  Outputs leave through a wave-private
+// 4 KiB transposition so that a store instruction writes 8 full 128-byte rows instead of 32 16-byte fragments.
+// Layouts (K image, V image, fragment and transposed reads, S^T / O^T accumulator geometry) are the tiled kernel's.
+// Measured at C2 (B = 256, H = 12, L = 197; tools/attn_bench.py, then in the model): 110 -> 86 us standalone, 92 -> 78 us
+// per layer inside ViT-B/16.  With the arithmetic switched off the kernel streams its 309 MB in 60 us (5.2 TB/s), with
+// the loads switched off it computes for 65 us (vector ALU ~45 % busy, matrix pipe 19 %: SQ counters); together 86 - the
+// per-head barrier drains the CU's load queue once per head.  Tried on top and dropped: waves 4-7 delayed by the QK^T phase
+// (so one wave of a SIMD pair issues MFMAs while the other is in its exponentials): 91 us; keeping the four output stores in
+// flight across the barrier by counting (vmcnt(4)): no change against storing the previous head's rows after the barrier.
+//
+// LDS-DMA that hipcc does not see.  With the builtin form it orders every later ds_read_b64_tr_b16 (an intrinsic without a
+// memory operand: "may alias") behind a vmcnt(0) of its own - the next head's prefetch then never overlaps this head's
+// arithmetic.  Hidden, the completion is ours to count: the vmcnt wait in
+// front of the per-head barrier.  (cdna_hip_programming.md, inline-asm rules: M0 written in the statement that reads it.)
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_dst_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q, int64_t qsb, int64_t qst,
+                                                      const bf16* __restrict__ K, int64_t ksb, int64_t kst,
+                                                      const bf16* __restrict__ V, int64_t vsb, int64_t vst,
+                                                      bf16* __restrict__ O, int64_t osb, int64_t ost, int H, int Lq,
+                                                      int Lk, int nheads) {
+  constexpr int ROWS = NB * 32, IMG = ROWS * 128, BUF = 2 * IMG;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF + 8 * 4096];  // [buf][K image, V image] + staging per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int qi = wave * 32 + r;
+  const int qi_ld = qi < Lq ? qi : Lq - 1;
+  const bool live = wave * 32 < Lq;
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+  char* const stg = smem + 2 * BUF + wave * 4096;
+  const unsigned lds0 = (unsigned)(uintptr_t)(PM_LDS char*)smem;
+
+  // K / V rows of one head straight into LDS: NB pieces (8 rows of 128 bytes) per wave, the swizzles ride on the SOURCE
+  // chunk; rows past Lk repeat row Lk - 1 (finite values under probabilities that are exactly 0)
+#define PM_AH_ISSUE(HEAD, BUFI)                                                                                  \
+  {                                                                                                              \
+    const int b_ = (HEAD) / H, h_ = (HEAD) - b_ * H;                                                             \
+    const bf16* Kp_ = K + (int64_t)b_ * ksb + h_ * 64;                                                           \
+    const bf16* Vp_ = V + (int64_t)b_ * vsb + h_ * 64;                                                           \
+    const unsigned base_ = lds0 + (BUFI) * BUF;                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                             \
+      const int pi = wave + 8 * i;                                                                               \
+      const bool isv = pi >= 4 * NB;                                                                             \
+      const int piece = isv ? pi - 4 * NB : pi;                                                                  \
+      const int row = piece * 8 + (lane >> 3), pos = lane & 7;                                                   \
+      const int src = row < Lk ? row : Lk - 1;                                                                   \
+      const bf16* g_ = !isv ? Kp_ + (int64_t)src * kst + swz_pos(row, pos) * 8                                     \
+                            : Vp_ + (int64_t)src * vst + (pos ^ (((row >> 1) & 1) << 2)) * 8;                     \
+      glds16_hidden(g_, base_ + (isv ? IMG : 0) + piece * 1024);                                                 \
+    }                                                                                                            \
+  }
+#define PM_AH_LOADQ(HEAD, DST)                                                                                   \
+  {                                                                                                              \
+    const int b_ = (HEAD) / H, h_ = (HEAD) - b_ * H;                                                             \
+    const bf16* Qp_ = Q + (int64_t)b_ * qsb + h_ * 64 + (int64_t)qi_ld * qst + hh * 8;                           \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) DST[s] = *(const bf16x8*)(Qp_ + s * 16);                       \
+  }
+
+#define PM_AH_STORE(HEAD)                                                                                        \
+  {                                                                                                              \
+    const int b_ = (HEAD) / H, h_ = (HEAD) - b_ * H;                                                             \
+    bf16* op_ = O + (int64_t)b_ * osb + h_ * 64 + (lane & 7) * 8;                                                \
+    _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) {                                                           \
+      const int row = k4 * 8 + (lane >> 3);                                                                      \
+      const bf16x8 o = *(const bf16x8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) * 16));                      \
+      if (wave * 32 + row < Lq) *(bf16x8*)(op_ + (int64_t)(wave * 32 + row) * ost) = o;                          \
+    }                                                                                                            \
+  }
+
+  int head = blockIdx.x;
+  if (head >= nheads) return;
+  bf16x8 qf[4], qn[4];
+  PM_AH_ISSUE(head, 0)
+  PM_AH_LOADQ(head, qf)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qn[s] = qf[s];
+  for (int it = 0; head < nheads; ++it, head += gridDim.x) {
+    const int bufi = it & 1;
+    // this wave's pieces of `head` (and its queries) have landed; everything else it has in flight is a head old
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // ... everyone's have; and everyone is done with the other buffer
+    const int nxt = head + gridDim.x;
+    if (nxt < nheads) {
+      PM_AH_ISSUE(nxt, bufi ^ 1)
+      PM_AH_LOADQ(nxt, qn)
+    }
+    // the PREVIOUS head's rows leave now, from the wave's staging area: their stores drain under this head's arithmetic
+    // instead of in front of the next wait
+    if (live && it > 0) PM_AH_STORE(head - (int)gridDim.x)
+    if (live) {
+      const char* kimg = smem + bufi * BUF;
+      const char* vimg = kimg + IMG;
+      // ---- S^T = K Q^T, all NB blocks
+      f32x16 sc[NB];
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+        const int row = kb * 32 + r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bf16x8 kf = *(const bf16x8*)(kimg + row * 128 + swz_pos(row, 2 * s + hh) * 16);
+          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[kb], 0, 0, 0);
+        }
+      }
+      if (Lk < ROWS) {  // keys past Lk: last block only (the dispatcher picks the smallest NB that covers Lk)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = (NB - 1) * 32 + 4 * hh + (i & 3) + 8 * (i >> 2);
+          if (key >= Lk) sc[NB - 1][i] = -1e30f;
+        }
+      }
+      // ---- exact softmax: max of the raw scores, the scale rides in the exponent's fma
+      float mx = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kb][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mc = mx * c;
+      f32x2 ps2 = {0.f, 0.f};  // two chains for the row sum
+      f32x16 oacc[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+      // ---- O^T = V^T P^T in 16-key steps, each block's exponentials right in front of its MFMAs
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          // the last block's groups of 4 registers whose keys (8 gq + 0..7 of the block, both lane halves) do not exist
+          // carry no exponentials at all (wave-uniform): L = 197 evaluates 4 of that block's 16
+          const bool none = kb == NB - 1 && kb * 32 + 8 * gq >= Lk;
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {  // two scores per packed fma / add (v_pk_fma_f32, v_pk_add_f32)
+            const f32x2 a = __builtin_elementwise_fma(f32x2{sc[kb][4 * gq + e], sc[kb][4 * gq + e + 1]}, f32x2{c, c}, f32x2{-mc, -mc});
+            f32x2 p;
+            p[0] = none ? 0.f : __builtin_amdgcn_exp2f(a[0]);
+            p[1] = none ? 0.f : __builtin_amdgcn_exp2f(a[1]);
+            sc[kb][4 * gq + e] = p[0];
+            sc[kb][4 * gq + e + 1] = p[1];
+            ps2 += p;
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (kb == NB - 1 && (kb * 32 + 16 * s) >= Lk) continue;  // 16 keys that do not exist (wave-uniform)
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (bf16)sc[kb][8 * s + j];
+          const int row = kb * 32 + 16 * s + 4 * (g >> 1) + qq;
+          const int flip = ((row >> 1) & 1) << 2;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int ch = db * 4 + 2 * (g & 1) + (pp >> 1);
+            const char* p0 = vimg + row * 128 + ((ch ^ flip) * 16) + (pp & 1) * 8;
+            const bf16x8 vf = tr_read_pair(p0, p0 + 8 * 128);
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+          }
+        }
+      }
+      const float ps = ps2[0] + ps2[1];
+      const float inv = 1.0f / (ps + __shfl_xor(ps, 32, 64));
+      // ---- O^T (query on the lane) -> row-major rows through the wave's own 4 KiB: chunk c of query row q at c ^ (q & 7)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * gq + j] * inv);
+          *(bf16x4*)(stg + r * 128 + (((db * 4 + gq) ^ (r & 7)) * 16) + hh * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+  }
+  if (live) PM_AH_STORE(head - (int)gridDim.x)  // the last head of this workgroup
+#undef PM_AH_STORE
+#undef PM_AH_ISSUE
+#undef PM_AH_LOADQ
+}
+
 }  // namespace
 
 static int attention_impl(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k, int64_t k_stride_b,
@@ -265,6 +467,36 @@ static int attention_impl(const void* q, int64_t q_stride_b, int64_t q_stride_t,
   hipLaunchKernelGGL((attn_fwd_hd64<C_, B_>), dim3((unsigned)nblk), dim3(256), 0, st, (const bf16*)q, q_stride_b, q_stride_t, \
                      (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t, (bf16*)o, o_stride_b,  \
                      o_stride_t, (int)H, (int)Lq, (int)Lk, nqb, bias, bsb, bsh, bsq)
+  static const bool short_ok = [] { const char* e = getenv("PM_ATTN_SHORT"); return !e || atoi(e) != 0; }();
+  if (short_ok && !causal && !bias && Lk <= 256 && Lq <= 256 && !((o_stride_t | o_stride_b) % 8) && !((uintptr_t)o & 15)) {
+    // short self-attention: one persistent workgroup per CU walks the heads (K / V of a head in LDS once, one-pass softmax)
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    const int64_t nheads = B * H;
+    if (nheads > 0x7fffffff) return PM_EINVAL;
+    const unsigned grid = (unsigned)(nheads < cus ? nheads : cus);
+    const int nb = (int)((Lk + 31) / 32);
+#define PM_ATTS(NB_)                                                                                                     \
+  hipLaunchKernelGGL((attn_head_hd64<NB_>), dim3(grid), dim3(512), 0, st, (const bf16*)q, q_stride_b, q_stride_t,          \
+                     (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t, (bf16*)o, o_stride_b, \
+                     o_stride_t, (int)H, (int)Lq, (int)Lk, (int)nheads)
+    switch (nb) {
+      case 1: PM_ATTS(1); break;
+      case 2: PM_ATTS(2); break;
+      case 3: PM_ATTS(3); break;
+      case 4: PM_ATTS(4); break;
+      case 5: PM_ATTS(5); break;
+      case 6: PM_ATTS(6); break;
+      case 7: PM_ATTS(7); break;
+      default: PM_ATTS(8); break;
+    }
+#undef PM_ATTS
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+  }
   if (causal && bias) PM_ATT(true, true);
   else if (causal) PM_ATT(true, false);
   else if (bias) PM_ATT(false, true);

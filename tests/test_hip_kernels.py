@@ -223,6 +223,33 @@ def test_attention_noncausal(ops, B, H, Lq, Lk):
     close_bf16(got, ref_attn(q, k, v, H, False), rel=1.5e-2)
 
 
+@pytest.mark.parametrize("Lk", [1, 5, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 96, 127, 128, 160, 197, 208, 209, 224, 225, 255, 256, 257])
+def test_attention_short_key_sequences(ops, Lk):
+    """Every 32-key block count of the whole-K/V-in-LDS kernel (Lk <= 256: one-pass softmax), block and 16-key step edges,
+    and the first length past it (tiled kernel); queries spanning two workgroups with a ragged last wave."""
+    B, H, Lq = 2, 2, 165
+    q = bf(synth_input("as_q", (B, Lq, H * 64), 130 + Lk))
+    k = bf(synth_input("as_k", (B, Lk, H * 64), 131 + Lk))
+    v = bf(synth_input("as_v", (B, Lk, H * 64), 132 + Lk))
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    close_bf16(got, ref_attn(q, k, v, H, False), rel=1.5e-2)
+    again = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 1, 197), (2, 3, 32, 197), (2, 3, 33, 40), (1, 2, 255, 256), (3, 2, 256, 197),
+                                       (70, 12, 70, 70), (300, 3, 5, 33)])
+def test_attention_short_heads_walk(ops, B, H, Lq, Lk):
+    """The persistent per-head kernel: query-count edges, and more (batch, head) pairs than workgroups so that every
+    workgroup walks several heads through both LDS buffers."""
+    q = bf(synth_input("ah_q", (B, Lq, H * 64), 140))
+    k = bf(synth_input("ah_k", (B, Lk, H * 64), 141))
+    v = bf(synth_input("ah_v", (B, Lk, H * 64), 142))
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    close_bf16(got, ref_attn(q, k, v, H, False), rel=1.5e-2)
+    assert torch.equal(got, ops.attention(q.cuda(), k.cuda(), v.cuda(), H))
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk", [(2, 2, 4, 4), (1, 3, 200, 200), (2, 1, 448, 448), (1, 2, 6, 9), (1, 1, 130, 40), (1, 1, 1, 5)])
 def test_attention_causal_top_left(ops, B, H, Lq, Lk):
     """causal is top-left aligned, including rectangular Lq != Lk."""

@@ -17,7 +17,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "attn_fwd" in r["Kernel_Name"]:
+        if "attn_fwd" in r["Kernel_Name"] or "attn_head" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:32s} {sum(v)/len(v):18.1f}  (n={len(v)})")
