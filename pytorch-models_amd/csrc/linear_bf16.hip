@@ -28,7 +28,9 @@ bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act);
 // linear_bf16_sk.hip
 int pm_linear_bf16_sk_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                              int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
-                             int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, void* ws, hipStream_t st);
+                             int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, void* ws, hipStream_t st,
+                             int mode);
+bool pm_linear_bf16_hyb_applies(int64_t M, int64_t N, int64_t K, int act);
 bool pm_linear_bf16_sk_applies(int64_t M, int64_t N, int64_t K, int act);
 int64_t pm_linear_sk_ws_bytes();
 
@@ -505,17 +507,24 @@ int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int6
 // Stream-K form of the 256 x 256 kernel (linear_bf16_sk.hip): no round quantisation - its cost is the exact tile count over 256
 // plus the partial-tile exchange (one 256 KiB store and load per workgroup, ~a quarter of a K = 768 tile), taken when that
 // beats the best whole-tile kernel by 3 % (QKV at 6.93 rounds stays whole-tile; linear1 at 9.23, out_proj / linear2 at 2.31 move).
-enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3, PM_K_SK = 4 };
-static int pm_linear_pick_kernel(int64_t M, int64_t N, int64_t K, bool persist_ok, bool wide_ok, bool sk_ok, bool has_resid) {
-  static const int forced = [] { const char* e = getenv("PM_GEMM_KERNEL"); return e ? atoi(e) : 0; }();  // experiments: 1 .. 4
+// Hybrid form (linear_bf16_sk.hip, mode 1): the wide kernel's whole tiles + the last round's tiles in two K halves: its cost is
+// the whole rounds + half a round + the hand-off of one partial tile.
+enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3, PM_K_SK = 4, PM_K_HYB = 5 };
+static int pm_linear_pick_kernel(int64_t M, int64_t N, int64_t K, bool persist_ok, bool wide_ok, bool sk_ok, bool hyb_ok,
+                                 bool has_resid) {
+  static const int forced = [] { const char* e = getenv("PM_GEMM_KERNEL"); return e ? atoi(e) : 0; }();  // experiments: 1 .. 5
   // OFF unless PM_GEMM_STREAMK=1: measured on MI355X (tools/sk_check.py, us, whole-tile 256 x 256 kernel -> stream-K): out_proj
   // 96 -> 118, linear2 316 -> 339, linear1 + GELU 335 -> 352, QKV 196 -> 224, 8192^3 851 -> 935.  The balance is real (every
   // workgroup issues the same MFMAs) but each launch moves 64 MB of fp32 partial tiles out and back (one per workgroup:
   // ~25 us), and contiguous per-workgroup ranges lose the L2 sharing of interleaved neighbouring tiles (-10 % in the K loop).
   static const bool use_sk = [] { const char* e = getenv("PM_GEMM_STREAMK"); return e && atoi(e) != 0; }();
   if (!use_sk && forced != PM_K_SK) sk_ok = false;
+  static const bool use_hyb = [] { const char* e = getenv("PM_GEMM_HYBRID"); return !e || atoi(e) != 0; }();
+  if (!use_hyb && forced != PM_K_HYB) hyb_ok = false;
   if (forced == PM_K_SK && sk_ok) return PM_K_SK;
+  if (forced == PM_K_HYB && hyb_ok) return PM_K_HYB;
   if (forced && forced != PM_K_SK) sk_ok = false;
+  if (forced && forced != PM_K_HYB) hyb_ok = false;
   if (forced == PM_K_WIDE && wide_ok) return PM_K_WIDE;
   if (forced == PM_K_PERSIST && persist_ok) return PM_K_PERSIST;
   if (forced == PM_K_SMALL) return PM_K_SMALL;
@@ -533,7 +542,9 @@ static int pm_linear_pick_kernel(int64_t M, int64_t N, int64_t K, bool persist_o
   const double cw = wide_ok ? rounds(tw, 256, 1.0) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
   const double csk = sk_ok ? (tw / 256.0 + 0.25 * 768.0 / (double)K) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
   const double best = cw < cp ? (cw < cs ? cw : cs) : (cp < cs ? cp : cs);
-  if (csk < 0.97 * best) return PM_K_SK;
+  const double chyb = hyb_ok ? ((double)(int64_t)(tw / 256.0) + 0.5 + 0.25 * 768.0 / (double)K) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
+  if (csk < 0.97 * best && csk <= chyb) return PM_K_SK;
+  if (chyb < 0.97 * best) return PM_K_HYB;
   if (cw <= cp && cw <= cs) return PM_K_WIDE;
   return cp <= cs ? PM_K_PERSIST : PM_K_SMALL;
 }
@@ -569,17 +580,19 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
                      pm_linear_bf16_sk_applies(M, N, K, act) && !(ln.row_out && act != PM_ACT_NONE);
   const bool persist_ok = (K % BK == 0) && (M >= 4096) && (y_dtype == PM_F32 || !vec_ok || out_vec16);
   const bool staged_ok = persist_ok && y_dtype == PM_BF16 && vec_ok && !(resid && resid_dtype == PM_F32);
+  const bool hyb_ok = wide_base && ws && ws_bytes >= pm_linear_sk_ws_bytes() && !((uintptr_t)ws & 15) &&
+                      pm_linear_bf16_hyb_applies(M, N, K, act) && !(ln.row_out && act != PM_ACT_NONE);
   int kernel;
   if (want_ln) {  // the LayerNorm fold lives in the persistent kernels' staged epilogues (row partials: 256 x 128 only)
     if (!staged_ok) return PM_EUNSUPPORTED;
-    kernel = pm_linear_pick_kernel(M, N, K, true, wide_ok, sk_ok, resid != nullptr);
+    kernel = pm_linear_pick_kernel(M, N, K, true, wide_ok, sk_ok, hyb_ok, resid != nullptr);
     if (kernel == PM_K_SMALL) kernel = PM_K_PERSIST;
   } else {
-    kernel = pm_linear_pick_kernel(M, N, K, persist_ok, wide_ok, sk_ok, resid != nullptr);
+    kernel = pm_linear_pick_kernel(M, N, K, persist_ok, wide_ok, sk_ok, hyb_ok, resid != nullptr);
   }
-  if (kernel == PM_K_SK) {
+  if (kernel == PM_K_SK || kernel == PM_K_HYB) {
     const int rck = pm_linear_bf16_sk_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
-                                             ldy, M, N, K, act, ln, ws, st0);
+                                             ldy, M, N, K, act, ln, ws, st0, kernel == PM_K_HYB ? 1 : 0);
     if (rck != PM_OK) return rck;
     PM_CHECK_LAUNCH();
     return PM_OK;

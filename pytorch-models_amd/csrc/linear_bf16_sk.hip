@@ -18,6 +18,12 @@
 // depend on who finishes; the finisher zeroes the ticket for the next launch (MI355X_MICROARCH.md, inter-workgroup
 // visibility: counter told by the value an add returned / an sc1 load of it, workgroup barrier between that and every
 // sc1 load of the bytes).  Workspace = caller-owned: pm_linear_sk_workspace_bytes().
+// HYBRID mode (mode = 1; the default use of this kernel): whole tiles dealt out exactly as linear_bf16_wide.hip deals them
+// (workgroup l of an XCD takes tiles l, l + 32, ... of the XCD's chunk: neighbours share panels in L2) and only the
+// rem = tiles mod 32 tiles of the last, partly filled round are cut - in two K halves, for workgroups 2u and 2u + 1:
+// 2u + 1 computes the tile's last K steps FIRST (and publishes them), 2u its first K steps LAST (and finds them there): the
+// same two-party hand-off as above, one 256 KiB partial per tail tile and direction instead of one per workgroup, and a
+// last round that costs half a tile: N = 768 at M = 50432 runs 2.5 rounds instead of 3.  Needs 2 rem <= 32 per XCD.
 // The epilogue is the wide kernel's plus, in the RS instantiation, the LayerNorm fold's row partials (sum, sum of squares
 // of each row's ROUNDED outputs per 64-feature block) so that out_proj / linear2 of a fold chain can run here.
 #include <cstdlib>
@@ -53,7 +59,7 @@ template <int ACT, bool RS>
 __global__ __launch_bounds__(512, 2) void linear_bf16_sk_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
     const bf16* resid, int64_t ldr, int resid_period, bf16* Y, int64_t ldy, int M, int N, int K, int tiles_m, int tiles_n,
-    int x_rows_per_batch, int64_t x_batch_stride, PmLnFold ln, char* ws) {
+    int x_rows_per_batch, int64_t x_batch_stride, PmLnFold ln, char* ws, int mode) {
   __shared__ __attribute__((aligned(16))) char smem[2 * SSTAGE + 8 * 4096];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,18 +74,51 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_sk_kernel(
   const int cq = ntiles >> 3, cr = ntiles & 7;
   const int tbase = xcd * cq + (xcd < cr ? xcd : cr), tcount = cq + (xcd < cr ? 1 : 0);
   const int nk = K / SBK;
-  const int CS = tcount * nk;
-  const int s0 = (int)((int64_t)CS * local / nloc), s1 = (int)((int64_t)CS * (local + 1) / nloc);
-  const int P = s1 - s0;
   const int gid = xcd * nloc + local;  // boundary gid = start of this range, gid + 1 = its end
+  // this workgroup's sequence of tiles: sequence index -> tile id = tbase + (seq_mul * index + seq_add), except index
+  // tail_pos -> tail_id; the range = P steps starting at step kt0 of sequence index 0; late_start = the step at which the
+  // range's last, partial tile begins (-1: the range ends on a tile boundary)
+  int P, kt0, late_start, seq_mul, seq_add, tail_pos = -1, tail_id = 0;
+  if (mode == 0) {
+    const int CS = tcount * nk;
+    const int s0 = (int)((int64_t)CS * local / nloc), s1 = (int)((int64_t)CS * (local + 1) / nloc);
+    P = s1 - s0;
+    kt0 = s0 % nk;
+    late_start = (s1 % nk) ? P - (s1 % nk) : -1;
+    seq_mul = 1;
+    seq_add = s0 / nk;
+  } else {
+    const int R = tcount / nloc, rem = tcount - R * nloc, h = nk >> 1;
+    const int u = local >> 1;
+    const bool has_tail = u < rem;  // 2 rem <= nloc (checked on the host)
+    seq_mul = nloc;
+    seq_add = local;
+    P = R * nk;
+    kt0 = 0;
+    late_start = -1;
+    if (has_tail) {
+      tail_id = tbase + R * nloc + u;
+      if (local & 1) {  // the tile's steps [h, nk) at the START of the range
+        tail_pos = 0;
+        seq_add = local - nloc;  // whole tiles at sequence indices 1 .. R
+        kt0 = h;
+        P += nk - h;
+      } else {          // steps [0, h) at the END
+        tail_pos = R;
+        late_start = P;
+        P += h;
+      }
+    }
+  }
+#define PM_STILE(IDX) ((IDX) == tail_pos ? tail_id : tbase + seq_mul * (IDX) + seq_add)
 
   uint32_t xoff[4], woff[4];
-  int pp = 0, pp_kt = s0 % nk, pp_tile = s0 / nk, pp_buf = 0;
+  int pp = 0, pp_kt = kt0, pp_tile = 0, pp_buf = 0;
 #define PM_SSTAGE_NEXT()                                                                                             \
   if (pp < P) {                                                                                                      \
     if (pp_kt == 0 || pp == 0) {                                                                                     \
       int tm_, tn_;                                                                                                  \
-      stile_coords(tbase + pp_tile, tiles_m, tiles_n, tm_, tn_);                                                     \
+      stile_coords(PM_STILE(pp_tile), tiles_m, tiles_n, tm_, tn_);                                                     \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
         const int rt = wave * 32 + i * 8 + (lane >> 3);                                                              \
         const int chunk = swz_pos(rt, lane & 7);                                                                     \
@@ -114,8 +153,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_sk_kernel(
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the younger wave of each SIMD pair loses every arbitration otherwise
   PM_SSTAGE_NEXT();
   const int fr = lane & 15, fq = lane >> 4;
-  int buf = 0, kt = s0 % nk, ti = s0 / nk, seg_k0 = kt;
-  const int late_start = (s1 % nk) ? P - (s1 % nk) : -1;  // step at which this range's last, partial tile begins
+  int buf = 0, kt = kt0, ti = 0, seg_k0 = kt;
   bool seeded = false;
   f32x2 lnst[4] = {{0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}, {0.f, 1.f}};
   for (int pc = 0; pc < P; ++pc) {
@@ -158,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_sk_kernel(
     bool have_ln = false;
     if (kt == nk - 1 && ln.stats) {  // LayerNorm fold, last K step of the tile: (mean, rstd) of this lane's four token rows
       int tm_r, tn_r;
-      stile_coords(tbase + ti, tiles_m, tiles_n, tm_r, tn_r);
+      stile_coords(PM_STILE(ti), tiles_m, tiles_n, tm_r, tn_r);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int mr = tm_r * SBM + wm * 64 + i * 16 + fr;
@@ -188,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_sk_kernel(
 
     // ---------------- a segment [seg_k0, kt] of tile ti is complete
     int tm, tn;
-    stile_coords(tbase + ti, tiles_m, tiles_n, tm, tn);
+    stile_coords(PM_STILE(ti), tiles_m, tiles_n, tm, tn);
     bool do_epi = seg_k0 == 0 && tile_end;
     if (!do_epi) {
       const bool early = seg_k0 > 0;  // the tile's last K steps, computed at the start of this range
@@ -317,6 +355,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_sk_kernel(
       for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #undef PM_SSTAGE_NEXT
+#undef PM_STILE
 }
 
 }  // namespace
@@ -332,14 +371,25 @@ bool pm_linear_bf16_sk_applies(int64_t M, int64_t N, int64_t K, int act) {
   return ntiles / 8 >= SK_GRID / 8;  // the smallest XCD chunk has at least one tile per workgroup of the XCD
 }
 
+// Hybrid mode: whole tiles as the wide kernel + the last round's tiles in two K halves.  Eligible when every XCD's chunk
+// leaves at most 16 tiles over (a pair of workgroups per tail tile) and a K half exists.
+bool pm_linear_bf16_hyb_applies(int64_t M, int64_t N, int64_t K, int act) {
+  if (!pm_linear_bf16_sk_applies(M, N, K, act) || K / SBK < 2) return false;
+  const int64_t ntiles = ((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
+  const int64_t cq = ntiles >> 3, cr = ntiles & 7;
+  const int64_t rem_hi = (cq + (cr ? 1 : 0)) % (SK_GRID / 8), rem_lo = cq % (SK_GRID / 8);
+  return 2 * rem_hi <= SK_GRID / 8 && 2 * rem_lo <= SK_GRID / 8 && (rem_hi > 0 || rem_lo > 0);
+}
+
 int pm_linear_bf16_sk_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                              int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
-                             int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, void* ws, hipStream_t st) {
+                             int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, void* ws, hipStream_t st,
+                             int mode) {
   const int tiles_m = (int)((M + SBM - 1) / SBM), tiles_n = (int)((N + SBN - 1) / SBN);
 #define PM_SGO(A, R)                                                                                                     \
   hipLaunchKernelGGL((linear_bf16_sk_kernel<A, R>), dim3(SK_GRID), dim3(512), 0, st, (const bf16*)x, ldx, (const bf16*)w, ldw, \
                      bias, (const bf16*)resid, ldr, (int)resid_period, (bf16*)y, ldy, (int)M, (int)N, (int)K, tiles_m,     \
-                     tiles_n, (int)x_rows_per_batch, x_batch_stride, ln, (char*)ws)
+                     tiles_n, (int)x_rows_per_batch, x_batch_stride, ln, (char*)ws, mode)
   if (ln.row_out) {
     if (act != PM_ACT_NONE) return PM_EUNSUPPORTED;
     PM_SGO(PM_ACT_NONE, true);

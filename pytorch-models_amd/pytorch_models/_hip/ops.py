@@ -117,13 +117,15 @@ def gemm_workspace(device: torch.device) -> tuple[int, int]:
     return hit[0].data_ptr(), hit[1]
 
 
-_USE_STREAMK = os.environ.get("PM_GEMM_STREAMK", "0") != "0" or os.environ.get("PM_GEMM_KERNEL") == "4"
+_USE_WS = os.environ.get("PM_GEMM_HYBRID", "1") != "0" or os.environ.get("PM_GEMM_STREAMK", "0") != "0" or \
+    os.environ.get("PM_GEMM_KERNEL") in ("4", "5")
 
 
 def _ws_args(M: int, device: torch.device):
-    """The stream-K kernel is opt-in (PM_GEMM_STREAMK=1: measured slower than whole tiles on this repo's shapes, see
-    csrc/linear_bf16.hip): without it no workspace is allocated and pm_linear_bf16_ws behaves as pm_linear_bf16_ln."""
-    return gemm_workspace(device) if (_USE_STREAMK and M >= 4096) else (None, 0)
+    """Workspace for the GEMMs that cut tiles along K (csrc/linear_bf16_sk.hip): the hybrid form - whole tiles plus the last
+    round's tiles in two K halves, on by default - and the opt-in stream-K form (PM_GEMM_STREAMK=1).  One per device,
+    allocated at the first large-M call; without it pm_linear_bf16_ws behaves as pm_linear_bf16_ln."""
+    return gemm_workspace(device) if (_USE_WS and M >= 4096) else (None, 0)
 
 
 def _linear_bytes(x: Tensor, w: Tensor, out: Tensor, resid: Tensor | None) -> float:
