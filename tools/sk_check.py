@@ -2,9 +2,10 @@
 its two K ranges separately), closeness to an fp32 reference is; plus timings of the ViT-B/16 shapes with each kernel."""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-models_amd")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-models_amd"), os.path.join(ROOT, "tools")]
 import torch
 from pytorch_models._hip import ops
+from _timing import time_us
 torch.manual_seed(0)
 which = os.environ.get("PM_GEMM_KERNEL", "auto")
 for (M, N, K, act, resid) in [(50432, 768, 768, "none", True), (50432, 768, 3072, "none", True), (50432, 3072, 768, "gelu", False),
@@ -23,10 +24,5 @@ for (M, N, K, act, resid) in [(50432, 768, 768, "none", True), (50432, 768, 3072
         ref = ref + r[rows].float()
     err = (out[rows].float() - ref).abs().max().item()
     rel = ((out[rows].float() - ref).norm() / ref.norm()).item()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        ops.linear(x, w, b, act=act, resid=r, out=out)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
+    us = time_us(lambda: ops.linear(x, w, b, act=act, resid=r, out=out))
     print(f"kernel={which} M={M} N={N} K={K} act={act} resid={resid}: {us:7.1f} us {2*M*N*K/us/1e6:7.1f} TF  max|err| {err:.3e} rel {rel:.2e} rerun-identical {bool(torch.equal(out, out2))}", flush=True)
