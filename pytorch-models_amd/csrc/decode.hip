@@ -350,6 +350,218 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The vocabulary projection of a step (final LayerNorm + logits + per-tile arg-max) as a PERSISTENT kernel: the step's fattest
+// launch after the cross-attention blocks.  As dec_linear_kernel<.., ARGMAX> it ran ceil(V / 64) workgroups that EACH loaded
+// and normalised all of x (64 KB of fp32 for 32 rows of 512: as many bytes as the workgroup's weight rows; 52 + 53 MB per
+// launch through the CUs' load paths, 26.9 us at Whisper-base).  Here a workgroup normalises x ONCE, keeps its three bf16
+// terms in registers and walks vocabulary tiles: 32 weight rows per inner step, the next step's rows requested before this
+// step's MFMAs, partial sums of the four waves (each owns every fourth K step, as in dec_linear_kernel) through a double-buffered
+// LDS area - one barrier per step, wave 0 reduces step s while everyone computes s + 1.  Every sum is formed in
+// dec_linear_kernel's order, so the logits and the (max, index) pairs are bit-identical to that kernel's.
+template <int MT>
+__global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         const bf16* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias, int M, int N, int K,
+                                                         float* __restrict__ ws_val, int* __restrict__ ws_idx, int ntiles,
+                                                         int halves) {
+  constexpr int NSTEP = 4, GBK = 128 * NSTEP;
+  __shared__ float part[4 * 64];
+  __shared__ float gb[2 * GBK];
+  __shared__ __attribute__((aligned(16))) float red[2][4 * 2 * MT * 64 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fi = lane & 15, kq = lane >> 4;
+  const int ksteps = K >> 5;
+
+  // ---- x: this wave's K steps of every row, LayerNorm (the reference's two-pass statistics), three bf16 terms
+  f32x4 xv[NSTEP][MT][2];
+#pragma unroll
+  for (int u = 0; u < NSTEP; ++u) {
+    int s = wave + 4 * u;
+    s = s < ksteps ? s : ksteps - 1;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      int row = t * 16 + fi;
+      row = row < M ? row : M - 1;
+      const float* xr = x + (int64_t)row * ldx + kq * 8 + s * 32;
+      xv[u][t][0] = *(const f32x4*)xr;
+      xv[u][t][1] = *(const f32x4*)(xr + 4);
+    }
+  }
+  for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
+  float mean[MT], rstd[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    float sm = 0.f;
+#pragma unroll
+    for (int u = 0; u < NSTEP; ++u)
+      if (wave + 4 * u < ksteps) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm += xv[u][t][0][i] + xv[u][t][1][i];
+      }
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    if (kq == 0) part[wave * 64 + t * 16 + fi] = sm;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int r = t * 16 + fi;
+    mean[t] = ((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NSTEP; ++u)
+      if (wave + 4 * u < ksteps) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d0 = xv[u][t][0][i] - mean[t], d1 = xv[u][t][1][i] - mean[t];
+          q = fmaf(d0, d0, q);
+          q = fmaf(d1, d1, q);
+        }
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (kq == 0) part[wave * 64 + t * 16 + fi] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int r = t * 16 + fi;
+    rstd[t] = rsqrtf(((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K + eps);
+  }
+  bf16x8 xh[NSTEP][MT], xm[NSTEP][MT], xl[NSTEP][MT];
+#pragma unroll
+  for (int u = 0; u < NSTEP; ++u) {
+    int s = wave + 4 * u;
+    s = s < ksteps ? s : ksteps - 1;
+    const int k0 = s * 32 + kq * 8;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = xv[u][t][0][i]; v[4 + i] = xv[u][t][1][i]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gb[k0 + i] + gb[GBK + k0 + i];
+      split3(v, xh[u][t], xm[u][t], xl[u][t]);
+    }
+  }
+
+  // ---- vocabulary tiles: inner step q = (tile, half): 32 weight rows
+  const int total = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x * halves;  // inner steps of this workgroup
+  const int tile_feats = halves * 32;
+  auto wrow_ptr = [&](int q, int f) {
+    const int tile = blockIdx.x + (q / halves) * gridDim.x, hs = q - (q / halves) * halves;
+    int n = tile * tile_feats + hs * 32 + f * 16 + fi;
+    n = n < N ? n : N - 1;
+    return W + (int64_t)n * ldw + kq * 8;
+  };
+  bf16x8 a[NSTEP][2], an[NSTEP][2];
+  if (total > 0) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const bf16* wp = wrow_ptr(0, f);
+#pragma unroll
+      for (int u = 0; u < NSTEP; ++u) {
+        int s = wave + 4 * u;
+        s = s < ksteps ? s : ksteps - 1;
+        a[u][f] = *(const bf16x8*)(wp + s * 32);
+      }
+    }
+  }
+  float best_v[MT];
+  int best_i[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) { best_v[t] = -INFINITY; best_i[t] = 0x7fffffff; }
+#pragma unroll 1
+  for (int q = 0; q < total; ++q) {
+    if (q + 1 < total) {  // the next step's weight rows fly during this step's MFMAs
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const bf16* wp = wrow_ptr(q + 1, f);
+#pragma unroll
+        for (int u = 0; u < NSTEP; ++u) {
+          int s = wave + 4 * u;
+          s = s < ksteps ? s : ksteps - 1;
+          an[u][f] = *(const bf16x8*)(wp + s * 32);
+        }
+      }
+    }
+    f32x4 acc[2][MT];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NSTEP; ++u) {
+      if (wave + 4 * u >= ksteps) break;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], xh[u][t], acc[f][t], 0, 0, 0);
+          acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], xm[u][t], acc[f][t], 0, 0, 0);
+          acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], xl[u][t], acc[f][t], 0, 0, 0);
+        }
+    }
+    float* rb = red[q & 1];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) *(f32x4*)(rb + (((wave * 2 + f) * MT + t) * 64 + lane) * 4) = acc[f][t];
+    lds_barrier();  // (not __syncthreads: the next step's weight loads stay in flight)
+    if (wave == 0) {
+      const int tile = blockIdx.x + (q / halves) * gridDim.x, hs = q - (q / halves) * halves;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int n = tile * tile_feats + hs * 32 + f * 16 + kq * 4;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = *(const f32x4*)(rb + (((0 * 2 + f) * MT + t) * 64 + lane) * 4);
+#pragma unroll
+          for (int w = 1; w < 4; ++w) v += *(const f32x4*)(rb + (((w * 2 + f) * MT + t) * 64 + lane) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int nn = n + r;
+            if (nn >= N) continue;
+            const float e = v[r] + (bias ? bias[nn] : 0.f);
+            if (e > best_v[t]) { best_v[t] = e; best_i[t] = nn; }  // ascending nn: strict > keeps the lowest index
+          }
+        }
+      }
+      if (hs == halves - 1) {  // the arg-max tile is complete: winner over the 4 lanes sharing a sequence, publish, reset
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          float bv = best_v[t];
+          int bi = best_i[t];
+#pragma unroll
+          for (int o = 16; o < 64; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+          }
+          const int row = t * 16 + fi;
+          if (kq == 0 && row < M) {
+            ws_val[(int64_t)row * ntiles + tile] = bv;
+            ws_idx[(int64_t)row * ntiles + tile] = bi;
+          }
+          best_v[t] = -INFINITY;
+          best_i[t] = 0x7fffffff;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NSTEP; ++u)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) a[u][f] = an[u][f];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dec_embed_kernel(const int64_t* __restrict__ tok, const bf16* __restrict__ E,
                                                         const float* __restrict__ pos, const int* __restrict__ pos_ptr,
                                                         float* __restrict__ x, int B, int d, int V) {
@@ -1048,7 +1260,23 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
   static const bool rowsplit = [] { const char* e = getenv("PM_DEC_ROWSPLIT"); return !e || atoi(e) != 0; }();
   unsigned gz = 1;
   if (rowsplit && mode != DL_ARGMAX && mt > 1 && nwg * mt <= 512) { gz = (unsigned)mt; mt = 1; }
-  if (mode == DL_ARGMAX && ft == 2)
+  static const bool logits_persist = [] { const char* e = getenv("PM_DEC_LOGITS_PERSIST"); return !e || atoi(e) != 0; }();
+  if (mode == DL_ARGMAX && logits_persist && gamma && M <= 32 && per_wave <= 4 && nwg >= 64) {
+    // final LayerNorm + vocabulary projection + arg-max tiles as one persistent launch (dec_logits_kernel); the arg-max tiles
+    // and their workspace layout are this function's (pm_dec_argmax_tile)
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    const int grid = nwg < 2 * cus ? nwg : 2 * cus;
+    if (mt <= 1)
+      hipLaunchKernelGGL((dec_logits_kernel<1>), dim3(grid), dim3(256), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias,
+                         (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, ft / 2);
+    else
+      hipLaunchKernelGGL((dec_logits_kernel<2>), dim3(grid), dim3(256), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias,
+                         (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, ft / 2);
+  } else if (mode == DL_ARGMAX && ft == 2)
     rc = dl_launch<PM_ACT_NONE, 2>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                               (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
                               (int)Tmax, (const int*)pos_ptr, ws_val, (int*)ws_idx, nwg);

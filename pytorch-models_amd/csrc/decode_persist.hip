@@ -299,9 +299,12 @@ __device__ __forceinline__ void ps_attn_task(const PsArgs& p, PsLds& s, int b, i
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   auto pv = [&](const bf16x8& vv, int key) {
-    const float pe = key < Lc ? s.sc[key] : 0.f;
+    // a row that does not exist contributes NOTHING - not 0 * v: at the first self-attention step (Lc = 0) the clamped loads
+    // above read cache row 0 before anybody has written it, and 0 * NaN of recycled memory poisoned every later step
+    const bool ok = key < Lc;
+    const float pe = ok ? s.sc[key] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fmaf(pe, (float)vv[i], acc[i]);
+    for (int i = 0; i < 8; ++i) acc[i] = ok ? fmaf(pe, (float)vv[i], acc[i]) : acc[i];
   };
   if (wave != 0) {
 #pragma unroll

@@ -18,7 +18,7 @@
 // depend on who finishes; the finisher zeroes the ticket for the next launch (MI355X_MICROARCH.md, inter-workgroup
 // visibility: counter told by the value an add returned / an sc1 load of it, workgroup barrier between that and every
 // sc1 load of the bytes).  Workspace = caller-owned: pm_linear_sk_workspace_bytes().
-// HYBRID mode (mode = 1; the default use of this kernel): whole tiles dealt out exactly as linear_bf16_wide.hip deals them
+// HYBRID mode (mode = 1; opt-in, PM_GEMM_HYBRID=1: see pm_linear_pick_kernel for why it is not the default): whole tiles dealt out exactly as linear_bf16_wide.hip deals them
 // (workgroup l of an XCD takes tiles l, l + 32, ... of the XCD's chunk: neighbours share panels in L2) and only the
 // rem = tiles mod 32 tiles of the last, partly filled round are cut - in two K halves, for workgroups 2u and 2u + 1:
 // 2u + 1 computes the tile's last K steps FIRST (and publishes them), 2u its first K steps LAST (and finds them there): the

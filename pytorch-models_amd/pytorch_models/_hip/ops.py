@@ -117,14 +117,16 @@ def gemm_workspace(device: torch.device) -> tuple[int, int]:
     return hit[0].data_ptr(), hit[1]
 
 
-_USE_WS = os.environ.get("PM_GEMM_HYBRID", "1") != "0" or os.environ.get("PM_GEMM_STREAMK", "0") != "0" or \
+_USE_WS = os.environ.get("PM_GEMM_HYBRID", "0") != "0" or os.environ.get("PM_GEMM_STREAMK", "0") != "0" or \
     os.environ.get("PM_GEMM_KERNEL") in ("4", "5")
 
 
 def _ws_args(M: int, device: torch.device):
-    """Workspace for the GEMMs that cut tiles along K (csrc/linear_bf16_sk.hip): the hybrid form - whole tiles plus the last
-    round's tiles in two K halves, on by default - and the opt-in stream-K form (PM_GEMM_STREAMK=1).  One per device,
-    allocated at the first large-M call; without it pm_linear_bf16_ws behaves as pm_linear_bf16_ln."""
+    """Workspace for the GEMMs that cut tiles along K (csrc/linear_bf16_sk.hip), both opt-in: the hybrid form (PM_GEMM_HYBRID=1:
+    whole tiles plus the last round's tiles in two K halves) and stream-K (PM_GEMM_STREAMK=1).  Neither is on by default: a
+    tile cut along K sums differently from a whole one, so a sample's rounding would depend on its position in the batch.
+    One workspace per device and stream, allocated at the first large-M call; without it pm_linear_bf16_ws behaves as
+    pm_linear_bf16_ln."""
     return gemm_workspace(device) if (_USE_WS and M >= 4096) else (None, 0)
 
 
