@@ -171,7 +171,7 @@ int pm_attention_bias_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t
                            int64_t B, int64_t H, int64_t Lq, int64_t Lk, int causal, const float* bias,
                            int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream);
 
-/* Attention for head dims other than 64 (8..128, % 8 == 0; e.g. ViT-H's 80): same addressing with h*head_dim head
+/* Attention for head dims other than 64 (4..128, % 4 == 0; e.g. ViT-H's 80, MobileViT's 36 / 48 / 60): same addressing with h*head_dim head
  * offsets, optional additive bias (NULL = none), Lk <= 2048.  fp32 VALU, correctness-first, off the benchmark path. */
 int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t,
                               const void* k, int64_t k_stride_b, int64_t k_stride_t,

@@ -1,5 +1,6 @@
-// attention_generic.hip - scaled dot-product attention for head dims other than 64 (8 .. 128, multiple of 8), e.g. the
-// 80-wide heads of ViT-H (pytorch_models/image/vit.py:106-113: H = (32, 1280, 16)) or 16 / 32-wide heads of small MHAs.
+// attention_generic.hip - scaled dot-product attention for head dims other than 64 (4 .. 128, multiple of 4), e.g. the
+// 80-wide heads of ViT-H (pytorch_models/image/vit.py:106-113: H = (32, 1280, 16)), 16 / 32-wide heads of small MHAs, the
+// 36 / 48 / 60-wide heads of MobileViT's encoders (pytorch_models/image/mobile_vit.py:7: d = 144 / 192 / 240, 4 heads).
 // (reference: F.scaled_dot_product_attention at pytorch_models/transformer.py:52, same addressing as attention_bf16.hip)
 //
 // Correctness-first and off the benchmark path (every BASELINE config has head_dim 64): fp32 VALU arithmetic, a
@@ -26,13 +27,28 @@ __device__ __forceinline__ void ld8(const T* p, float (&o)[8]) {
 }
 
 template <typename T>
+__device__ __forceinline__ void ld4(const T* p, float (&o)[8]) {  // four values (head dims that are multiples of 4 only)
+  if constexpr (sizeof(T) == 2) {
+    const bf16x4 v = *(const bf16x4*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (float)v[e];
+  } else {
+    const f32x4 a = *(const f32x4*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e];
+  }
+#pragma unroll
+  for (int e = 4; e < 8; ++e) o[e] = 0.f;
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void attn_generic_kernel(const T* __restrict__ Q, int64_t qsb, int64_t qst,
                                                            const T* __restrict__ K, int64_t ksb, int64_t kst,
                                                            const T* __restrict__ V, int64_t vsb, int64_t vst,
                                                            T* __restrict__ O, int64_t osb, int64_t ost, int H, int Lq,
                                                            int Lk, int hd, int nqb, int causal,
                                                            const float* __restrict__ bias, int64_t bsb, int64_t bsh,
-                                                           int64_t bsq, float scale) {
+                                                           int64_t bsq, float scale, int step) {
   __shared__ float sc[GQ * GMAXK];
   __shared__ float qs[GQ * GMAXD];
   __shared__ float inv_sum[GQ];
@@ -56,14 +72,27 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T* __restrict__
 #pragma unroll
     for (int qq = 0; qq < GQ; ++qq) acc[qq] = 0.f;
     const T* kr = Kp + (int64_t)key * kst;
-    for (int d0 = 0; d0 < hd; d0 += 8) {
-      float kv[8];
-      ld8(kr + d0, kv);
+    if (step == 8) {
+      for (int d0 = 0; d0 < hd; d0 += 8) {
+        float kv[8];
+        ld8(kr + d0, kv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float kf = kv[e];
+        for (int e = 0; e < 8; ++e) {
+          const float kf = kv[e];
 #pragma unroll
-        for (int qq = 0; qq < GQ; ++qq) acc[qq] = fmaf(qs[qq * GMAXD + d0 + e], kf, acc[qq]);
+          for (int qq = 0; qq < GQ; ++qq) acc[qq] = fmaf(qs[qq * GMAXD + d0 + e], kf, acc[qq]);
+        }
+      }
+    } else {  // head dims 4 (mod 8), or rows aligned to 4 elements only: the same sums in the same order, 4 values per load
+      for (int d0 = 0; d0 < hd; d0 += 4) {
+        float kv[8];
+        ld4(kr + d0, kv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float kf = kv[e];
+#pragma unroll
+          for (int qq = 0; qq < GQ; ++qq) acc[qq] = fmaf(qs[qq * GMAXD + d0 + e], kf, acc[qq]);
+        }
       }
     }
 #pragma unroll
@@ -134,10 +163,13 @@ extern "C" int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int6
                                          int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream) {
   if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0 || head_dim <= 0) return PM_EINVAL;
   if (B == 0 || Lq == 0) return PM_OK;
-  if (head_dim % 8 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
-  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 8) return PM_EALIGN;
+  if (head_dim % 4 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
+  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 4) return PM_EALIGN;
   if ((o_stride_t | o_stride_b) % 4) return PM_EALIGN;
-  if (((uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return PM_EALIGN;
+  if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 7) return PM_EALIGN;
+  // 16-byte key loads where rows allow it (head_dim and every stride a multiple of 8 elements, 16-byte bases), 8-byte ones otherwise
+  const int step = (head_dim % 8 == 0 && !((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 8) &&
+                    !(((uintptr_t)k | (uintptr_t)v) & 15)) ? 8 : 4;
   if (bias && bias_stride_q < Lk) return PM_EINVAL;
   const int nqb = (int)((Lq + GQ - 1) / GQ);
   const int64_t nblk = B * H * nqb;
@@ -145,13 +177,13 @@ extern "C" int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int6
   hipLaunchKernelGGL(attn_generic_kernel<bf16>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const bf16*)q, q_stride_b,
                      q_stride_t, (const bf16*)k, k_stride_b, k_stride_t, (const bf16*)v, v_stride_b, v_stride_t, (bf16*)o,
                      o_stride_b, o_stride_t, (int)H, (int)Lq, (int)Lk, (int)head_dim, nqb, causal, bias, bias_stride_b,
-                     bias_stride_h, bias_stride_q, 1.0f / sqrtf((float)head_dim));
+                     bias_stride_h, bias_stride_q, 1.0f / sqrtf((float)head_dim), step);
   PM_CHECK_LAUNCH();
   return PM_OK;
 }
 
 /* The same kernel on fp32 operands (strides in ELEMENTS): attention of modules whose parameters are fp32 and of the exact
- * Whisper pipeline.  q, k, v, o f32 with unit last stride; head_dim % 8 == 0 (<= 128), Lk <= 2048; strides multiples of 4. */
+ * Whisper pipeline.  q, k, v, o f32 with unit last stride; head_dim % 4 == 0 (<= 128), Lk <= 2048; strides multiples of 4. */
 extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int64_t q_stride_t, const float* k,
                                         int64_t k_stride_b, int64_t k_stride_t, const float* v, int64_t v_stride_b,
                                         int64_t v_stride_t, float* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
@@ -159,7 +191,7 @@ extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int6
                                         int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream) {
   if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0 || head_dim <= 0) return PM_EINVAL;
   if (B == 0 || Lq == 0) return PM_OK;
-  if (head_dim % 8 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
+  if (head_dim % 4 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
   if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b | o_stride_t | o_stride_b) % 4) return PM_EALIGN;
   if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return PM_EALIGN;
   if (bias && bias_stride_q < Lk) return PM_EINVAL;
@@ -169,7 +201,7 @@ extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int6
   hipLaunchKernelGGL(attn_generic_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, q, q_stride_b,
                      q_stride_t, k, k_stride_b, k_stride_t, v, v_stride_b, v_stride_t, o, o_stride_b, o_stride_t, (int)H,
                      (int)Lq, (int)Lk, (int)head_dim, nqb, causal, bias, bias_stride_b, bias_stride_h, bias_stride_q,
-                     1.0f / sqrtf((float)head_dim));
+                     1.0f / sqrtf((float)head_dim), head_dim % 8 == 0 ? 8 : 4);
   PM_CHECK_LAUNCH();
   return PM_OK;
 }

@@ -206,7 +206,7 @@ def linear_f32(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "
 
 def attention_f32(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = False, bias: Tensor | None = None) -> Tensor:
     """attention() on fp32 operands: q (B, Lq, H*hd), k / v (B, Lk, H*hd) f32 views with unit last stride -> (B, Lq, H*hd) f32.
-    head_dim % 8 == 0 (<= 128), Lk <= 2048; bias as in attention()."""
+    head_dim % 4 == 0 (<= 128), Lk <= 2048; bias as in attention()."""
     _cuda(q, k, v, bias)
     _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention_f32: operands must be (B, L, H*hd)")
     B, Lq, D = q.shape
@@ -286,7 +286,7 @@ def attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = Fals
     """q (B, Lq, H*hd), k / v (B, Lk, H*hd) bf16 views with unit last stride (e.g. column slices of a packed
     QKV projection) -> (B, Lq, H*hd) bf16, heads already merged.  bias: optional additive f32 (b, h, Lq, Lk) with
     b in {1, B}, h in {1, H} (size-1 dims broadcast).  head_dim 64 runs on the MFMA kernel, other head dims
-    (8..128, % 8 == 0) on the generic one."""
+    (4..128, % 4 == 0: also MobileViT's 36 / 48 / 60) on the generic one."""
     _cuda(q, k, v, bias)
     _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention: operands must be (B, L, H*hd)")
     B, Lq, D = q.shape

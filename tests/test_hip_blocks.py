@@ -187,6 +187,14 @@ def test_mha_other_head_dims_match_the_reference_goldens(golden):
     assert rel(m(bfc(q)), g["h2hd16_q"]) < 3e-2
     m, _ = prep(MHA(d, head_dim=32, bias=False), 24)
     assert rel(m(bfc(q), bfc(k)), g["hd32_nobias"]) < 3e-2
+    # MobileViT's encoders (image/mobile_vit.py:7: d = 144 / 192 / 240 with 4 heads = 36 / 48 / 60-wide heads: multiples of 4, not
+    # of 8), self- and cross-shaped, at a patch-count-like length
+    for dm in (144, 192, 240):
+        m, sd = prep(MHA(dm, n_heads=4), 29)
+        x = synth_input(f"mha_mv{dm}", (3, 256, dm), 9)
+        y = synth_input(f"mha_mvk{dm}", (3, 49, dm), 9)
+        assert rel(m(bfc(x)), RT.mha(sd, "", 4, x.to(torch.bfloat16).float())) < 2e-2
+        assert rel(m(bfc(x), bfc(y), causal=True), RT.mha(sd, "", 4, x.to(torch.bfloat16).float(), y.to(torch.bfloat16).float(), causal=True)) < 2e-2
     # ViT-H style 80-wide heads (vit.py:112) at a ViT-like length
     m, sd = prep(MHA(160, n_heads=2), 28)
     x = synth_input("mha_h80", (2, 257, 160), 9)
@@ -198,6 +206,6 @@ def test_uncovered_configurations_raise_instead_of_falling_back():
 
     x = torch.zeros(1, 4, 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(NotImplementedError, match="head_dim"):
-        MHA(64, n_heads=16).to(torch.bfloat16).cuda()(x)  # head_dim 4
+        MHA(64, n_heads=32).to(torch.bfloat16).cuda()(x)  # head_dim 2
     with pytest.raises(NotImplementedError, match="bf16 or fp32"):
         MHA(64).cuda().half()(x.half())

@@ -55,7 +55,8 @@ def test_linear_f32_window_form_is_a_strided_conv(ops):
     torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("hd,H,Lq,Lk,causal", [(64, 2, 70, 133, False), (16, 4, 6, 9, False), (64, 8, 1, 300, False), (32, 2, 50, 50, True), (80, 2, 9, 257, False)])
+@pytest.mark.parametrize("hd,H,Lq,Lk,causal", [(64, 2, 70, 133, False), (16, 4, 6, 9, False), (64, 8, 1, 300, False), (32, 2, 50, 50, True), (80, 2, 9, 257, False),
+                                                 (36, 4, 64, 64, False), (60, 4, 33, 40, True), (4, 2, 5, 7, False)])
 def test_attention_f32(ops, hd, H, Lq, Lk, causal):
     B, D = 2, H * hd
     q, k, v = (synth_input(f"af_{n}", (B, L, D), 11) for n, L in (("q", Lq), ("k", Lk), ("v", Lk)))
