@@ -29,7 +29,8 @@ class DecoderGenerator:
         # (generate.greedy_exact) for everything else the layer algebra covers - fp32 parameters, post-norm stacks (GPT) -
         # instead of the reference's O(T^2) full-prefix loop, which remains for top-k sampling on those models
         kv_ok = p0.dtype == torch.bfloat16 and all(l.pre_norm for l in self.model.layers)
-        room = self.model.pos_embs.shape[0] - n
+        # a model without a position table (anything that is not one of this package's decoders) has no length limit here
+        room = self.model.pos_embs.shape[0] - n if hasattr(self.model, "pos_embs") else max_tokens
         if topk <= 64 and hasattr(self.model, "generate") and kv_ok:
             out = self.model.generate(torch.tensor([tokens], device=device), min(max_tokens, room), topk=topk, seed=seed)[0].tolist()
             new = out[n:]

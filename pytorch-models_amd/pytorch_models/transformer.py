@@ -82,6 +82,8 @@ def require_bf16_params(module: nn.Module, who: str) -> None:
     """Model families whose own kernels exist in bf16 only (the wav2vec2 stems / positional convolutions, T5's RMS norm,
     GEGLU and bias gather): an fp32 instance is refused instead of being computed through bf16 copies."""
     p = next(module.parameters(), None)
+    if p is not None and not p.is_cuda:  # the device error first: a CPU model is refused for being on the CPU, whatever its dtype
+        raise RuntimeError(f"{who}: HIP devices only - this build has no CPU path (move the model and its inputs to the GPU)")
     if p is not None and p.dtype != torch.bfloat16:
         raise NotImplementedError(
             f"{who}: bf16 parameters only on this build (got {p.dtype}); call model.to(torch.bfloat16).  The fp32-accurate path "
