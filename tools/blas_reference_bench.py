@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--iters", type=int, default=150)  # tens of milliseconds per window: see tools/_timing.py
 ap.add_argument("--zeros", action="store_true")
 args = ap.parse_args()
 SHAPES = [(50432, 2304, 768), (50432, 768, 768), (50432, 3072, 768), (50432, 768, 3072), (8192, 8192, 8192), (48000, 1536, 512)]
@@ -18,7 +18,8 @@ for M, N, K in SHAPES:
     b = torch.randn(N, device="cuda").to(torch.bfloat16)
     if args.zeros:
         x.zero_(), w.zero_()
-    for _ in range(3):
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(100):
         F.linear(x, w, b)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
