@@ -171,7 +171,19 @@ int pm_attention_bias_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t
                            int64_t B, int64_t H, int64_t Lq, int64_t Lk, int causal, const float* bias,
                            int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream);
 
-/* Attention for head dims other than 64 (4..128, % 4 == 0; e.g. ViT-H's 80, MobileViT's 36 / 48 / 60): same addressing with h*head_dim head
+/* Small 2-D convolution on NHWC bf16 (reference: conv_norm_act / MBConv / MobileViTBlock, pytorch_models/image/mobile_vit.py:10-69:
+ * nn.Conv2d(bias=False) + eval-mode nn.BatchNorm2d [+ nn.SiLU], the norm folded into w and bias by the caller).
+ * x: bf16 (N, H, W, Cin); w: bf16 (Cout, kh, kw, Cin / groups); bias: f32 (Cout) or NULL; resid: bf16 like y or NULL (added
+ * after the activation); y: bf16 (N, Ho, Wo, Cout), Ho = (H + 2 pad - kh) / stride + 1.  groups divides Cin and Cout (1 = dense,
+ * Cin = depthwise).  act: PM_ACT_NONE | PM_ACT_SILU | PM_ACT_RELU.  Direct convolution, fp32 accumulation; off the benchmark path. */
+int pm_conv2d_nhwc_bf16(const void* x, int64_t N, int64_t H, int64_t W, int64_t Cin, const void* w, const float* bias,
+                        const void* resid, void* y, int64_t Cout, int64_t kh, int64_t kw, int64_t stride, int64_t pad,
+                        int64_t groups, int act, void* stream);
+
+/* y[n, c] = mean over r of x[n, r, c]: nn.AdaptiveAvgPool2d(1) + Flatten on NHWC rows (mobile_vit.py:100).  bf16 in / out. */
+int pm_mean_rows_bf16(const void* x, void* y, int64_t N, int64_t HW, int64_t C, void* stream);
+
+/* Attention for head dims other than 64 (% 4 == 0 up to 128, % 2 == 0 up to 64; e.g. ViT-H's 80, MobileViT's 16 .. 60): same addressing with h*head_dim head
  * offsets, optional additive bias (NULL = none), Lk <= 2048.  fp32 VALU, correctness-first, off the benchmark path. */
 int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int64_t q_stride_t,
                               const void* k, int64_t k_stride_b, int64_t k_stride_t,

@@ -1,6 +1,7 @@
-// attention_generic.hip - scaled dot-product attention for head dims other than 64 (4 .. 128, multiple of 4), e.g. the
+// attention_generic.hip - scaled dot-product attention for head dims other than 64 (multiples of 4 up to 128, multiples of 2 up to 64), e.g. the
 // 80-wide heads of ViT-H (pytorch_models/image/vit.py:106-113: H = (32, 1280, 16)), 16 / 32-wide heads of small MHAs, the
-// 36 / 48 / 60-wide heads of MobileViT's encoders (pytorch_models/image/mobile_vit.py:7: d = 144 / 192 / 240, 4 heads).
+// 16 .. 60-wide heads of MobileViT's encoders (pytorch_models/image/mobile_vit.py:62,106-108: d = 64 .. 240 over 4 heads: 20 and
+// 30 are multiples of 2 only).
 // (reference: F.scaled_dot_product_attention at pytorch_models/transformer.py:52, same addressing as attention_bf16.hip)
 //
 // Correctness-first and off the benchmark path (every BASELINE config has head_dim 64): fp32 VALU arithmetic, a
@@ -39,6 +40,21 @@ __device__ __forceinline__ void ld4(const T* p, float (&o)[8]) {  // four values
   }
 #pragma unroll
   for (int e = 4; e < 8; ++e) o[e] = 0.f;
+}
+
+template <typename T>
+__device__ __forceinline__ void ld2(const T* p, float (&o)[8]) {  // two values (head dims that are multiples of 2 only)
+  if constexpr (sizeof(T) == 2) {
+    const bf16x2 v = *(const bf16x2*)p;
+    o[0] = (float)v[0];
+    o[1] = (float)v[1];
+  } else {
+    const f32x2 a = *(const f32x2*)p;
+    o[0] = a[0];
+    o[1] = a[1];
+  }
+#pragma unroll
+  for (int e = 2; e < 8; ++e) o[e] = 0.f;
 }
 
 template <typename T>
@@ -83,6 +99,17 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T* __restrict__
           for (int qq = 0; qq < GQ; ++qq) acc[qq] = fmaf(qs[qq * GMAXD + d0 + e], kf, acc[qq]);
         }
       }
+    } else if (step == 2) {
+      for (int d0 = 0; d0 < hd; d0 += 2) {
+        float kv[8];
+        ld2(kr + d0, kv);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float kf = kv[e];
+#pragma unroll
+          for (int qq = 0; qq < GQ; ++qq) acc[qq] = fmaf(qs[qq * GMAXD + d0 + e], kf, acc[qq]);
+        }
+      }
     } else {  // head dims 4 (mod 8), or rows aligned to 4 elements only: the same sums in the same order, 4 values per load
       for (int d0 = 0; d0 < hd; d0 += 4) {
         float kv[8];
@@ -120,8 +147,29 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const T* __restrict__
     if (lane == 0) inv_sum[qq] = 1.0f / sum;
   }
   __syncthreads();
-  // ---- P.V: thread -> (query tid / 32, 4 dims (tid % 32) * 4)
-  const int qq = tid >> 5, d0 = (tid & 31) * 4;
+  // ---- P.V: thread -> (query tid / 32, 4 dims (tid % 32) * 4); head dims that are multiples of 2 only: 2 dims per thread
+  const int qq = tid >> 5;
+  if (step == 2) {
+    const int d0 = (tid & 31) * 2;
+    if (d0 < hd) {
+      float o[2] = {0.f, 0.f};
+      for (int key = 0; key < Lk; ++key) {
+        const float p = sc[qq * GMAXK + key];
+        float vv[8];
+        ld2(Vp + (int64_t)key * vst + d0, vv);
+        o[0] = fmaf(p, vv[0], o[0]);
+        o[1] = fmaf(p, vv[1], o[1]);
+      }
+      const int qi = q0 + qq;
+      if (qi < Lq) {
+        T* op = O + (int64_t)b * osb + (int64_t)qi * ost + (int64_t)h * hd + d0;
+        if constexpr (sizeof(T) == 2) *(bf16x2*)op = bf16x2{(bf16)(o[0] * inv_sum[qq]), (bf16)(o[1] * inv_sum[qq])};
+        else *(f32x2*)op = f32x2{o[0] * inv_sum[qq], o[1] * inv_sum[qq]};
+      }
+    }
+    return;
+  }
+  const int d0 = (tid & 31) * 4;
   if (d0 < hd) {
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     for (int key = 0; key < Lk; ++key) {
@@ -163,13 +211,14 @@ extern "C" int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int6
                                          int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream) {
   if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0 || head_dim <= 0) return PM_EINVAL;
   if (B == 0 || Lq == 0) return PM_OK;
-  if (head_dim % 4 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
-  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 4) return PM_EALIGN;
-  if ((o_stride_t | o_stride_b) % 4) return PM_EALIGN;
-  if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 7) return PM_EALIGN;
+  if (head_dim % 2 || head_dim > GMAXD || Lk > GMAXK || (head_dim % 4 && head_dim > 64)) return PM_EUNSUPPORTED;
+  const int unit = head_dim % 4 ? 2 : 4;  // elements per access of the narrowest path this head_dim needs
+  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b | o_stride_t | o_stride_b) % unit) return PM_EALIGN;
+  if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & (unit * 2 - 1)) return PM_EALIGN;
   // 16-byte key loads where rows allow it (head_dim and every stride a multiple of 8 elements, 16-byte bases), 8-byte ones otherwise
-  const int step = (head_dim % 8 == 0 && !((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 8) &&
-                    !(((uintptr_t)k | (uintptr_t)v) & 15)) ? 8 : 4;
+  const int step = unit == 2 ? 2
+                   : (head_dim % 8 == 0 && !((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b) % 8) &&
+                      !(((uintptr_t)k | (uintptr_t)v) & 15)) ? 8 : 4;
   if (bias && bias_stride_q < Lk) return PM_EINVAL;
   const int nqb = (int)((Lq + GQ - 1) / GQ);
   const int64_t nblk = B * H * nqb;
@@ -183,7 +232,7 @@ extern "C" int pm_attention_generic_bf16(const void* q, int64_t q_stride_b, int6
 }
 
 /* The same kernel on fp32 operands (strides in ELEMENTS): attention of modules whose parameters are fp32 and of the exact
- * Whisper pipeline.  q, k, v, o f32 with unit last stride; head_dim % 4 == 0 (<= 128), Lk <= 2048; strides multiples of 4. */
+ * Whisper pipeline.  q, k, v, o f32 with unit last stride; head_dim % 4 == 0 (<= 128) or % 2 == 0 (<= 64), Lk <= 2048; strides multiples of 4 (2). */
 extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int64_t q_stride_t, const float* k,
                                         int64_t k_stride_b, int64_t k_stride_t, const float* v, int64_t v_stride_b,
                                         int64_t v_stride_t, float* o, int64_t o_stride_b, int64_t o_stride_t, int64_t B,
@@ -191,9 +240,10 @@ extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int6
                                         int64_t bias_stride_b, int64_t bias_stride_h, int64_t bias_stride_q, void* stream) {
   if (!q || !k || !v || !o || B < 0 || H <= 0 || Lq < 0 || Lk <= 0 || head_dim <= 0) return PM_EINVAL;
   if (B == 0 || Lq == 0) return PM_OK;
-  if (head_dim % 4 || head_dim > GMAXD || Lk > GMAXK) return PM_EUNSUPPORTED;
-  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b | o_stride_t | o_stride_b) % 4) return PM_EALIGN;
-  if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return PM_EALIGN;
+  if (head_dim % 2 || head_dim > GMAXD || Lk > GMAXK || (head_dim % 4 && head_dim > 64)) return PM_EUNSUPPORTED;
+  const int unit32 = head_dim % 4 ? 2 : 4;
+  if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b | o_stride_t | o_stride_b) % unit32) return PM_EALIGN;
+  if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & (unit32 * 4 - 1)) return PM_EALIGN;
   if (bias && bias_stride_q < Lk) return PM_EINVAL;
   const int nqb = (int)((Lq + GQ - 1) / GQ);
   const int64_t nblk = B * H * nqb;
@@ -201,7 +251,7 @@ extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int6
   hipLaunchKernelGGL(attn_generic_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, q, q_stride_b,
                      q_stride_t, k, k_stride_b, k_stride_t, v, v_stride_b, v_stride_t, o, o_stride_b, o_stride_t, (int)H,
                      (int)Lq, (int)Lk, (int)head_dim, nqb, causal, bias, bias_stride_b, bias_stride_h, bias_stride_q,
-                     1.0f / sqrtf((float)head_dim), head_dim % 8 == 0 ? 8 : 4);
+                     1.0f / sqrtf((float)head_dim), head_dim % 4 ? 2 : head_dim % 8 == 0 ? 8 : 4);
   PM_CHECK_LAUNCH();
   return PM_OK;
 }

@@ -39,6 +39,8 @@ SIGNATURES = {
     "pm_embed_tokens": ([_p, _p, _p, _p, _i, _l, _l, _l, _l, _l, _p], c_int),
     "pm_embed_tokens_f32": ([_p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
     "pm_dec_embed": ([_p, _p, _p, _p, _p, _l, _l, _l, _p], c_int),
+    "pm_conv2d_nhwc_bf16": ([_p, _l, _l, _l, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _l, _i, _p], c_int),
+    "pm_mean_rows_bf16": ([_p, _p, _l, _l, _l, _p], c_int),
     "pm_dec_linear": ([_p, _l, _p, _p, _f, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _p, _p, _l, _l, _l, _p, _p, _p, _p], c_int),
     "pm_dec_argmax_tile": ([_l], c_int),
     "pm_dec_attention": ([_p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _p], c_int),

@@ -206,7 +206,7 @@ def linear_f32(x: Tensor, w: Tensor, bias: Tensor | None = None, *, act: str = "
 
 def attention_f32(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = False, bias: Tensor | None = None) -> Tensor:
     """attention() on fp32 operands: q (B, Lq, H*hd), k / v (B, Lk, H*hd) f32 views with unit last stride -> (B, Lq, H*hd) f32.
-    head_dim % 4 == 0 (<= 128), Lk <= 2048; bias as in attention()."""
+    head_dim % 4 == 0 (<= 128) or % 2 == 0 (<= 64), Lk <= 2048; bias as in attention()."""
     _cuda(q, k, v, bias)
     _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention_f32: operands must be (B, L, H*hd)")
     B, Lq, D = q.shape
@@ -286,7 +286,7 @@ def attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = Fals
     """q (B, Lq, H*hd), k / v (B, Lk, H*hd) bf16 views with unit last stride (e.g. column slices of a packed
     QKV projection) -> (B, Lq, H*hd) bf16, heads already merged.  bias: optional additive f32 (b, h, Lq, Lk) with
     b in {1, B}, h in {1, H} (size-1 dims broadcast).  head_dim 64 runs on the MFMA kernel, other head dims
-    (4..128, % 4 == 0: also MobileViT's 36 / 48 / 60) on the generic one."""
+    (% 4 == 0 up to 128, % 2 == 0 up to 64: MobileViT's 16 .. 60) on the generic one."""
     _cuda(q, k, v, bias)
     _need(q.dim() == 3 and k.dim() == 3 and v.dim() == 3, "attention: operands must be (B, L, H*hd)")
     B, Lq, D = q.shape
@@ -314,6 +314,38 @@ def attention(q: Tensor, k: Tensor, v: Tensor, n_heads: int, causal: bool = Fals
         rc = _launch("attention_bf16", 4.0 * B * n_heads * Lq * Lk * 64, lambda: lib().pm_attention_bias_bf16(
             *args, bias.data_ptr(), sb, sh, sq, _stream()))
     check(rc, f"pm_attention_bf16(B={B}, H={n_heads}, Lq={Lq}, Lk={Lk})")
+    return out
+
+
+def conv2d_nhwc(x: Tensor, w: Tensor, bias: Tensor | None, stride: int = 1, pad: int = 0, groups: int = 1, act: str = "none",
+                resid: Tensor | None = None) -> Tensor:
+    """x (N, H, W, Cin) bf16, w (Cout, kh, kw, Cin / groups) bf16 (a BatchNorm already folded in), bias f32 (Cout) ->
+    (N, Ho, Wo, Cout) bf16; optional residual of the output's shape added after the activation (pm_conv2d_nhwc_bf16)."""
+    _cuda(x, w, bias, resid)
+    _need(x.dim() == 4 and w.dim() == 4 and x.is_contiguous() and w.is_contiguous(), "conv2d_nhwc: contiguous NHWC x and (Cout, kh, kw, Cin/g) w")
+    _need(x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16, "conv2d_nhwc: bf16 operands")
+    N, H, W, Cin = x.shape
+    Cout, kh, kw, cg = w.shape
+    _need(Cin % groups == 0 and Cout % groups == 0 and cg == Cin // groups, "conv2d_nhwc: channel / group mismatch")
+    _need(bias is None or (bias.dtype == torch.float32 and bias.numel() == Cout), "conv2d_nhwc: bias must be f32 (Cout)")
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = torch.empty((N, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    _need(resid is None or (resid.shape == out.shape and resid.dtype == torch.bfloat16 and resid.is_contiguous()), "conv2d_nhwc: resid must match the output")
+    rc = _launch("conv2d_nhwc", 2.0 * N * Ho * Wo * Cout * kh * kw * cg, lambda: lib().pm_conv2d_nhwc_bf16(
+        x.data_ptr(), N, H, W, Cin, w.data_ptr(), bias.data_ptr() if bias is not None else None,
+        resid.data_ptr() if resid is not None else None, out.data_ptr(), Cout, kh, kw, stride, pad, groups, ACT[act], _stream()))
+    check(rc, f"pm_conv2d_nhwc_bf16(N={N}, H={H}, W={W}, Cin={Cin}, Cout={Cout}, k={kh}x{kw}, stride={stride}, groups={groups})")
+    return out
+
+
+def mean_rows(x: Tensor) -> Tensor:
+    """x (N, R, C) bf16 contiguous -> (N, C) bf16: the mean over the R rows of each sample (pm_mean_rows_bf16)."""
+    _cuda(x)
+    _need(x.dim() == 3 and x.is_contiguous() and x.dtype == torch.bfloat16, "mean_rows: contiguous bf16 (N, R, C)")
+    N, R, C = x.shape
+    out = torch.empty((N, C), dtype=torch.bfloat16, device=x.device)
+    rc = _launch("mean_rows", 1.0 * N * R * C, lambda: lib().pm_mean_rows_bf16(x.data_ptr(), out.data_ptr(), N, R, C, _stream()))
+    check(rc, f"pm_mean_rows_bf16(N={N}, R={R}, C={C})")
     return out
 
 

@@ -1,1 +1,2 @@
+from .mobile_vit import MobileViT
 from .vit import ViT

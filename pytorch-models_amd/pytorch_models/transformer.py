@@ -198,8 +198,8 @@ class MHA(nn.Module):
     def attend(self, q, k=None, v=None, attn_bias=None, causal=False, residual: Tensor | None = None) -> Tensor:
         """forward() plus an optional residual that is added inside the out_proj kernel's epilogue."""
         _require_bf16(q, self.q_proj.weight, "MHA")
-        if self.head_dim % 4 or self.head_dim > 128:
-            raise NotImplementedError(f"MHA: head_dim {self.head_dim} is not covered by the gfx950 attention kernels (4..128, % 4)")
+        if self.head_dim % 2 or self.head_dim > 128 or (self.head_dim % 4 and self.head_dim > 64):
+            raise NotImplementedError(f"MHA: head_dim {self.head_dim} is not covered by the gfx950 attention kernels (% 4 up to 128, % 2 up to 64)")
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("MHA: inference only (attention dropout is not implemented)")
         H, inner = self.n_heads, self.n_heads * self.head_dim

@@ -38,6 +38,8 @@ def _std_for(key: str, shape: tuple[int, ...]) -> tuple[float, float]:
         return 1.0, 0.1
     if leaf == "bias":
         return 0.0, 0.05
+    if leaf == "running_var":  # BatchNorm: a variance is positive
+        return 1.0, 0.1
     # pe, cls_token, probe, pos_embs and other free parameters / buffers
     return 0.0, 0.1
 

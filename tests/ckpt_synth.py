@@ -286,6 +286,66 @@ def t5x_flat(n_layers, dim, n_heads, mlp_dim, vocab, seed=0):
     return sd
 
 
+def apple_mobilevit(channels, d_models, out_dim, expansion, n_classes=10, seed=0):
+    """cvnets v0.1 MobileViT checkpoint (reference loader: pytorch_models/image/mobile_vit.py:125-196): `block.conv` / `block.norm`
+    pairs, MobileNetV2 blocks `exp_1x1 / conv_3x3 / red_1x1`, MobileViT blocks `local_rep / global_rep.{i} / conv_proj / fusion`
+    with a fused `qkv_proj`, and a classifier the loader drops."""
+    sd = {}
+
+    def put(k, shape):
+        sd[k] = _t(k, shape, seed)
+
+    def conv_norm(prefix, cin, cout, k, groups=1):
+        put(f"{prefix}.block.conv.weight", (cout, cin // groups, k, k))
+        put(f"{prefix}.block.norm.weight", (cout,))
+        put(f"{prefix}.block.norm.bias", (cout,))
+        put(f"{prefix}.block.norm.running_mean", (cout,))
+        put(f"{prefix}.block.norm.running_var", (cout,))
+        sd[f"{prefix}.block.norm.num_batches_tracked"] = torch.tensor(7)
+
+    def mbconv(prefix, cin, cout):
+        hid = cin * expansion
+        conv_norm(f"{prefix}.exp_1x1", cin, hid, 1)
+        conv_norm(f"{prefix}.conv_3x3", hid, hid, 3, groups=hid)
+        conv_norm(f"{prefix}.red_1x1", hid, cout, 1)
+
+    def vit_block(prefix, c, d, n_layers):
+        conv_norm(f"{prefix}.local_rep.conv_3x3", c, c, 3)
+        put(f"{prefix}.local_rep.conv_1x1.block.conv.weight", (d, c, 1, 1))
+        for i in range(n_layers):
+            p = f"{prefix}.global_rep.{i}"
+            put(f"{p}.pre_norm_mha.0.weight", (d,))
+            put(f"{p}.pre_norm_mha.0.bias", (d,))
+            put(f"{p}.pre_norm_mha.1.qkv_proj.weight", (3 * d, d))
+            put(f"{p}.pre_norm_mha.1.qkv_proj.bias", (3 * d,))
+            put(f"{p}.pre_norm_mha.1.out_proj.weight", (d, d))
+            put(f"{p}.pre_norm_mha.1.out_proj.bias", (d,))
+            put(f"{p}.pre_norm_ffn.0.weight", (d,))
+            put(f"{p}.pre_norm_ffn.0.bias", (d,))
+            put(f"{p}.pre_norm_ffn.1.weight", (2 * d, d))
+            put(f"{p}.pre_norm_ffn.1.bias", (2 * d,))
+            put(f"{p}.pre_norm_ffn.4.weight", (d, 2 * d))
+            put(f"{p}.pre_norm_ffn.4.bias", (d,))
+        put(f"{prefix}.global_rep.{n_layers}.weight", (d,))
+        put(f"{prefix}.global_rep.{n_layers}.bias", (d,))
+        conv_norm(f"{prefix}.conv_proj", d, c, 1)
+        conv_norm(f"{prefix}.fusion", 2 * c, c, 3)
+
+    conv_norm("conv_1", 3, 16, 3)
+    mbconv("layer_1.0.block", 16, channels[0])
+    mbconv("layer_2.0.block", channels[0], channels[1])
+    mbconv("layer_2.1.block", channels[1], channels[1])
+    mbconv("layer_2.2.block", channels[1], channels[1])
+    for name, cin, c, d, n in (("layer_3", channels[1], channels[2], d_models[0], 2), ("layer_4", channels[2], channels[3], d_models[1], 4),
+                               ("layer_5", channels[3], channels[4], d_models[2], 3)):
+        mbconv(f"{name}.0.block", cin, c)
+        vit_block(f"{name}.1", c, d, n)
+    conv_norm("conv_1x1_exp", channels[4], out_dim, 1)
+    put("classifier.fc.weight", (n_classes, out_dim))
+    put("classifier.fc.bias", (n_classes,))
+    return sd
+
+
 def state_digest(sd) -> dict:
     """name -> [sum, sum |x|, position-weighted sum] (fp64) of every tensor of a loaded model."""
     out = {}

@@ -495,9 +495,40 @@ def g_t5():
     save("t5", dict(dim=dim), **out)
 
 
+def g_mobile_vit():
+    """MobileViT xxs / xs / s (image/mobile_vit.py) on 64 x 64 images - the smallest side its five stride-2 stages and 2 x 2
+    patches allow -: the outputs of the five stages and the pooled features, every BatchNorm with non-trivial running
+    statistics; and a digest of what load_apple_state_dict makes of a synthetic cvnets checkpoint."""
+    from pytorch_models.image.mobile_vit import MobileViT
+
+    sys.path.insert(2, os.path.join(ROOT, "tests"))
+    import ckpt_synth as C
+
+    out, conv = {}, {}
+    x = synth_input("mv_x", (2, 3, 64, 64), 61)
+    for v in ("xxs", "xs", "s"):
+        m = MobileViT.from_apple(v).eval()
+        fill_module(m, 62)
+        h = x
+        for i in range(5):
+            h = m[i](h)
+            out[f"{v}_stage{i}"] = h if i < 2 else h  # small at this image size: kept whole
+        out[f"{v}_out"] = m[5](h)
+        assert torch.allclose(out[f"{v}_out"], m(x))
+        channels, d_models, out_dim, expansion = dict(
+            xxs=([16, 24, 48, 64, 80], [64, 80, 96], 320, 2), xs=([32, 48, 64, 80, 96], [96, 120, 144], 384, 4),
+            s=([32, 64, 96, 128, 160], [144, 192, 240], 640, 4))[v]
+        m2 = MobileViT.from_apple(v)
+        m2.load_apple_state_dict(C.apple_mobilevit(channels, d_models, out_dim, expansion, seed=63))
+        conv[v] = C.state_digest(m2.state_dict())
+    with open(os.path.join(HERE, "mobile_vit_converter.json"), "w") as f:
+        json.dump(conv, f, indent=0, sort_keys=True)
+    save("mobile_vit", dict(img=64), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters", "text", "audio_enc", "t5"]
+    which = sys.argv[1:] or ["blocks", "mha", "sdpa", "vit", "audio", "whisper", "geometry", "converters", "text", "audio_enc", "t5", "mobile_vit"]
     table = dict(blocks=g_blocks, mha=g_mha, sdpa=g_sdpa_alignment, vit=g_vit, audio=g_audio, whisper=g_whisper,
-                 geometry=g_geometry, converters=g_converters, text=g_text, audio_enc=g_audio_enc, t5=g_t5)
+                 geometry=g_geometry, converters=g_converters, text=g_text, audio_enc=g_audio_enc, t5=g_t5, mobile_vit=g_mobile_vit)
     for w in which:
         table[w]()
