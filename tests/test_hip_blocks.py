@@ -206,6 +206,10 @@ def test_uncovered_configurations_raise_instead_of_falling_back():
 
     x = torch.zeros(1, 4, 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(NotImplementedError, match="head_dim"):
-        MHA(64, n_heads=32).to(torch.bfloat16).cuda()(x)  # head_dim 2
+        MHA(66, n_heads=22).to(torch.bfloat16).cuda()(torch.zeros(1, 4, 66, dtype=torch.bfloat16, device="cuda"))  # head_dim 3: odd
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        MHA(140, n_heads=2).to(torch.bfloat16).cuda()(torch.zeros(1, 4, 140, dtype=torch.bfloat16, device="cuda"))  # 70: % 2 only, > 64
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        MHA(264, n_heads=2).to(torch.bfloat16).cuda()(torch.zeros(1, 4, 264, dtype=torch.bfloat16, device="cuda"))  # 132 > 128
     with pytest.raises(NotImplementedError, match="bf16 or fp32"):
         MHA(64).cuda().half()(x.half())
