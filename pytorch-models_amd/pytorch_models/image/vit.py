@@ -66,6 +66,7 @@ class ViT(nn.Module):
         self.cls_token = nn.Parameter(torch.zeros(1, 1, d_model)) if cls_token else None
         self.pe = nn.Parameter(torch.zeros(1, (img_size // patch_size) ** 2, d_model))
         self.layers = Encoder(n_layers, d_model, n_heads=n_heads, dropout=dropout, norm_eps=self.norm_eps)
+        self.layers.pm_streams = 2  # large batches run as two halves on two HIP streams (transformer.py, Encoder.forward)
         self.norm = LayerNorm(d_model, self.norm_eps)
         poolers = dict(
             cls_token=ClassTokenPooling,

@@ -52,6 +52,12 @@ def derived(module: nn.Module, key: str, params, build):
         with torch.no_grad():
             hit = (sig, build())
         store[key] = hit
+        # A derived tensor is built by kernels on whatever stream is current and then used from ANY stream (Encoder.forward
+        # runs the halves of a large batch on two): wait for the build once, here, instead of ordering every later use.
+        # (Not during a graph capture: captures are preceded by a warm-up that has built everything.)
+        if torch.cuda.is_available() and any(isinstance(p, Tensor) and p.is_cuda for p in params) and \
+                not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().synchronize()
     return hit[1]
 
 
@@ -62,6 +68,16 @@ def _f32(module: nn.Module, key: str, t: Tensor | None) -> Tensor | None:
 
 
 _FLOATS = (torch.bfloat16, torch.float32)
+_SIDE_STREAMS: dict = {}
+ENCODER_STREAMS = 0  # 0 = the instance / PM_ENCODER_STREAMS decide; 1 = one stream (bench.py's per-kernel timing pass sets it); 2 = two
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    """One extra HIP stream per device (Encoder.forward runs the second half of a large batch on it)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def _is32(p: Tensor) -> bool:
@@ -473,15 +489,63 @@ class Encoder(nn.Sequential):
         applies the LayerNorm in its epilogue - no LayerNorm kernel, no LN(x) round trip through HBM."""
         layers = list(self)
         fold = os.environ.get("PM_LN_FOLD", "1") != "0"
-        ok = [fold and isinstance(l, EncoderLayer) and type(l).forward is EncoderLayer.forward and l.chain_ok(x) for l in layers]
-        stats = None
-        for i, layer in enumerate(layers):
+
+        def plan(t: Tensor):
+            return [fold and isinstance(l, EncoderLayer) and type(l).forward is EncoderLayer.forward and l.chain_ok(t) for l in layers]
+
+        def step(i: int, ok, t: Tensor, stats):
             if not ok[i]:
-                x, stats = layer(x), None
-                continue
+                return layers[i](t), None
             nxt = layers[i + 1].sa_norm.eps if i + 1 < len(layers) and ok[i + 1] else None
-            x, stats = layer.forward_chain(x, stats, nxt)
-        return x
+            return layers[i].forward_chain(t, stats, nxt)
+
+        halves = self._two_streams(x)
+        if halves is not None and plan(halves[0]) != plan(halves[1]):
+            halves = None  # the two halves would take different paths (LayerNorm folded / not): keep the batch in one piece
+        if halves is None:
+            ok, stats = plan(x), None
+            for i in range(len(layers)):
+                x, stats = step(i, ok, x, stats)
+            return x
+        # Two halves of the batch on two HIP streams, layer by layer.  Samples are independent and every kernel is
+        # batch-position invariant, so the result is bit-identical; what changes is the schedule: the large-M kernels are
+        # persistent (one workgroup per CU) and their last round of tiles leaves most CUs idle - 2.31 rounds run as 3 at
+        # ViT-B/16's N = 768 -, and the other half's workgroups start on exactly those CUs.  The vendor library evens such rounds by
+        # cutting tiles along K; this evens them across two kernels with whole tiles (DESIGN.md section 8).
+        cur = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device)
+        out = torch.empty_like(x)  # allocated on the caller's stream BEFORE the fork: every tensor the side stream allocates
+        side.wait_stream(cur)      # also dies on it, so the caching allocator needs no cross-stream bookkeeping (record_stream)
+        streams = (cur, side)
+        state = [(h, None) for h in halves]
+        oks = [plan(h) for h in halves]
+        n0 = halves[0].shape[0]
+        for i in range(len(layers)):
+            for k in (1, 0):
+                with torch.cuda.stream(streams[k]):
+                    state[k] = step(i, oks[k], state[k][0], state[k][1])
+                    if i == len(layers) - 1:
+                        (out[n0:] if k else out[:n0]).copy_(state[k][0])
+                        state[k] = None
+        cur.wait_stream(side)
+        return out
+
+    pm_streams = 1  # 2 on instances whose owner opts in (ViT): see _two_streams
+
+    def _two_streams(self, x: Tensor):
+        """The two halves of a batch that is worth splitting - a 3-D (batch, tokens, d) bf16 input on a HIP device with at least
+        32768 rows, where the persistent GEMM / attention kernels run - or None.  Opt-in per instance (`pm_streams = 2`: ViT sets
+        it; PM_ENCODER_STREAMS=2 sets it everywhere, =1 or the module switch ENCODER_STREAMS = 1 nowhere).  Not the default for
+        every encoder: with HIP-graph replays queued behind it on the caller's stream - Whisper's decode steps, when the host runs
+        ahead of the GPU - the fork's cross-stream wait makes every one of those replays slower (measured: +9 ms per 227-replay
+        step against 0.15 ms gained in the encoder; with a host synchronisation per step, or no graphs, it costs nothing)."""
+        want = ENCODER_STREAMS or int(os.environ.get("PM_ENCODER_STREAMS", "0")) or self.pm_streams
+        if want < 2 or not x.is_cuda or x.dim() != 3 or x.shape[0] < 2:
+            return None
+        if x.dtype != torch.bfloat16 or x.shape[0] * x.shape[1] < 32768:
+            return None
+        h = (x.shape[0] + 1) // 2
+        return [x[:h], x[h:]]
 
 
 class Decoder(nn.ModuleList):

@@ -130,3 +130,36 @@ def test_vit_other_patch_sizes_dinov2_p14(golden):
         t = m.to(torch.bfloat16).cuda().tokens(x.cuda())
         want = RV.tokens(sd, x.to(torch.bfloat16).float())
         torch.testing.assert_close(t.float().cpu(), want, rtol=1e-2, atol=2e-2)
+
+
+def test_two_stream_encoder_is_bit_identical_and_graph_capturable():
+    """ViT's encoder runs a large batch as two halves on two HIP streams (transformer.py, Encoder.forward): the same bits as the two halves computed one after the other,
+    on the first call too (derived weights are built on one stream and used from both), with an odd batch, and inside a
+    captured HIP graph (fork / join of the side stream within the capture)."""
+    from pytorch_models import transformer as tf
+    from pytorch_models.graph import GraphedForward
+    from pytorch_models.image import ViT
+
+    m = ViT.from_google("Ti/16").eval()
+    fill_module(m, 7)
+    m = m.to(torch.bfloat16).cuda()
+    x = synth_input("ts_x", (171, 3, 224, 224), 8).cuda()  # 171 x 197 = 33687 rows: above the split threshold, odd batch
+    with torch.no_grad():
+        two = m(x)  # first call of this model: builds its derived tensors while forked
+        tf.ENCODER_STREAMS = 1
+        try:
+            one = m(x)
+            halves = torch.cat([m(x[:86]), m(x[86:])])  # what the two streams compute, one after the other on one stream
+        finally:
+            tf.ENCODER_STREAMS = 0
+        assert torch.isfinite(two.float()).all() and torch.equal(two, m(x))
+        assert torch.equal(two, halves)  # streams change the schedule, not a bit
+        # against the unsplit batch the path may differ with M exactly as between two batch sizes (LayerNorm folded into the
+        # GEMMs or not, by pm_linear_ln_supported): the same function within the model's bf16 noise (ViT-B/16 at batch 256:
+        # identical bits, tools/two_stream_vit.py)
+        print(f"two-stream vs unsplit: identical {bool(torch.equal(one, two))}, max |diff| {float((one.float() - two.float()).abs().max()):.3e}")
+        assert float((one.float() - two.float()).norm() / one.float().norm()) < 3e-2
+        g = GraphedForward(m, x)
+        assert torch.equal(g(x), two)
+        x2 = synth_input("ts_x2", (171, 3, 224, 224), 9).cuda()
+        assert torch.equal(g(x2), m(x2))
