@@ -72,9 +72,9 @@ _SIDE_STREAMS: dict = {}
 ENCODER_STREAMS = 0  # 0 = the instance / PM_ENCODER_STREAMS decide; 1 = one stream (bench.py's per-kernel timing pass sets it); 2 = two
 
 
-def _side_stream(device: torch.device) -> "torch.cuda.Stream":
-    """One extra HIP stream per device (Encoder.forward runs the second half of a large batch on it)."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def _side_stream(device: torch.device, k: int = 1) -> "torch.cuda.Stream":
+    """Extra HIP stream k of a device (Encoder.forward runs the later parts of a large batch on them)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), k)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
@@ -500,8 +500,8 @@ class Encoder(nn.Sequential):
             return layers[i].forward_chain(t, stats, nxt)
 
         halves = self._two_streams(x)
-        if halves is not None and plan(halves[0]) != plan(halves[1]):
-            halves = None  # the two halves would take different paths (LayerNorm folded / not): keep the batch in one piece
+        if halves is not None and any(plan(h) != plan(halves[0]) for h in halves[1:]):
+            halves = None  # the parts would take different paths (LayerNorm folded / not): keep the batch in one piece
         if halves is None:
             ok, stats = plan(x), None
             for i in range(len(layers)):
@@ -513,21 +513,24 @@ class Encoder(nn.Sequential):
         # ViT-B/16's N = 768 -, and the other half's workgroups start on exactly those CUs.  The vendor library evens such rounds by
         # cutting tiles along K; this evens them across two kernels with whole tiles.
         cur = torch.cuda.current_stream(x.device)
-        side = _side_stream(x.device)
-        out = torch.empty_like(x)  # allocated on the caller's stream BEFORE the fork: every tensor the side stream allocates
-        side.wait_stream(cur)      # also dies on it, so the caching allocator needs no cross-stream bookkeeping (record_stream)
-        streams = (cur, side)
+        streams = [cur] + [_side_stream(x.device, k) for k in range(1, len(halves))]
+        out = torch.empty_like(x)  # allocated on the caller's stream BEFORE the fork: every tensor a side stream allocates
+        for st in streams[1:]:     # also dies on it, so the caching allocator needs no cross-stream bookkeeping (record_stream)
+            st.wait_stream(cur)
         state = [(h, None) for h in halves]
         oks = [plan(h) for h in halves]
-        n0 = halves[0].shape[0]
+        first = [0]
+        for h in halves:
+            first.append(first[-1] + h.shape[0])
         for i in range(len(layers)):
-            for k in (1, 0):
+            for k in reversed(range(len(halves))):
                 with torch.cuda.stream(streams[k]):
                     state[k] = step(i, oks[k], state[k][0], state[k][1])
                     if i == len(layers) - 1:
-                        (out[n0:] if k else out[:n0]).copy_(state[k][0])
+                        out[first[k] : first[k + 1]].copy_(state[k][0])
                         state[k] = None
-        cur.wait_stream(side)
+        for st in streams[1:]:
+            cur.wait_stream(st)
         return out
 
     pm_streams = 1  # 2 on instances whose owner opts in (ViT): see _two_streams
@@ -544,8 +547,9 @@ class Encoder(nn.Sequential):
             return None
         if x.dtype != torch.bfloat16 or x.shape[0] * x.shape[1] < 32768:
             return None
-        h = (x.shape[0] + 1) // 2
-        return [x[:h], x[h:]]
+        want = min(want, 4, x.shape[0])
+        cuts = [x.shape[0] * k // want for k in range(want + 1)]
+        return [x[cuts[k] : cuts[k + 1]] for k in range(want)]
 
 
 class Decoder(nn.ModuleList):
