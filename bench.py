@@ -163,7 +163,9 @@ def run_vit(args, rank, world, device):
                            "algorithmic_bytes_per_launch": round(lin["bytes"] / lin["n"]) if lin.get("bytes") else None,
                            "launches": lin["n"], "avg_launch_us": round(1e3 * lin["ms"] / lin["n"], 2),
                            "note": "per-kernel HIP-event timing of K extra steps with the encoder on one stream (full-M launches, "
-                                   "no overlap); the timed region runs the product default: the two halves of the batch on two streams"}
+                                   "no overlap: rocprofv3 summary of `PM_ENCODER_STREAMS=1 python bench.py` = "
+                                   "profiles/r02/bench_one_stream_kernel_stats.csv); the timed region runs the product default - the "
+                                   "two halves of the batch on two streams (profiles/r02/bench_both_legs_kernel_stats.csv)"}
         res["kernels"] = {k: {"launches": v["n"], "total_ms": round(v["ms"], 3)} for k, v in kern.items()}
         res["model_tflops"] = round(vit_flops_per_image() * B * args.steps / dt / 1e12, 1)
         res["model_frac_of_peak"] = round(res["model_tflops"] / PEAK_BF16_TFLOPS, 4)
