@@ -111,7 +111,14 @@ class ViT(nn.Module):
         return y
 
     def forward(self, imgs: Tensor) -> Tensor:
-        out = self.layers(self.tokens(imgs))
+        n_tok = self.pe.shape[1] + (self.cls_token is not None)
+        parts = None
+        if imgs.dim() == 4 and imgs.is_cuda and self.patch_embed.weight.dtype == torch.bfloat16:
+            parts = self.layers.split_sizes(imgs.shape[0], n_tok, torch.bfloat16, imgs.device)
+        if parts is None:
+            out = self.layers(self.tokens(imgs))
+        else:  # a large batch: each part's patch projection runs on the stream its encoder layers run on
+            out = self.layers(producers=[lambda lo=lo, hi=hi: self.tokens(imgs[lo:hi]) for lo, hi in parts], device=imgs.device)
         io = self.patch_embed.weight.dtype  # bf16 model -> bf16 features, fp32 model -> fp32 features
         if isinstance(self.pooler, ClassTokenPooling):
             # LayerNorm is row-wise, so normalising only the pooled row equals norm-then-pool (vit.py:83-84)

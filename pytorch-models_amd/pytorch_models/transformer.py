@@ -483,10 +483,11 @@ class Encoder(nn.Sequential):
             for _ in range(n_layers)
         ])
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor | None = None, *, producers=None, device: torch.device | None = None) -> Tensor:
         """The layers in order.  Runs of plain pre-norm layers at GEMM-sized M are chained: each residual GEMM
         (out_proj, linear2) also emits the row statistics of its output, and the next GEMM (q/k/v, linear1)
-        applies the LayerNorm in its epilogue - no LayerNorm kernel, no LN(x) round trip through HBM."""
+        applies the LayerNorm in its epilogue - no LayerNorm kernel, no LN(x) round trip through HBM.
+        ``producers`` (instead of x): one callable per batch part (split_sizes), each called on its part's stream."""
         layers = list(self)
         fold = os.environ.get("PM_LN_FOLD", "1") != "0"
 
@@ -499,10 +500,10 @@ class Encoder(nn.Sequential):
             nxt = layers[i + 1].sa_norm.eps if i + 1 < len(layers) and ok[i + 1] else None
             return layers[i].forward_chain(t, stats, nxt)
 
-        halves = self._two_streams(x)
+        halves = self._two_streams(x) if producers is None else None
         if halves is not None and any(plan(h) != plan(halves[0]) for h in halves[1:]):
             halves = None  # the parts would take different paths (LayerNorm folded / not): keep the batch in one piece
-        if halves is None:
+        if halves is None and producers is None:
             ok, stats = plan(x), None
             for i in range(len(layers)):
                 x, stats = step(i, ok, x, stats)
@@ -512,18 +513,35 @@ class Encoder(nn.Sequential):
         # persistent (one workgroup per CU) and their last round of tiles leaves most CUs idle - 2.31 rounds run as 3 at
         # ViT-B/16's N = 768 -, and the other half's workgroups start on exactly those CUs.  The vendor library evens such rounds by
         # cutting tiles along K; this evens them across two kernels with whole tiles.
-        cur = torch.cuda.current_stream(x.device)
-        streams = [cur] + [_side_stream(x.device, k) for k in range(1, len(halves))]
-        out = torch.empty_like(x)  # allocated on the caller's stream BEFORE the fork: every tensor a side stream allocates
-        for st in streams[1:]:     # also dies on it, so the caching allocator needs no cross-stream bookkeeping (record_stream)
+        n_parts = len(halves) if producers is None else len(producers)
+        device = halves[0].device if producers is None else device
+        cur = torch.cuda.current_stream(device)
+        streams = [cur] + [_side_stream(device, k) for k in range(1, n_parts)]
+        for st in streams[1:]:
             st.wait_stream(cur)
-        state = [(h, None) for h in halves]
-        oks = [plan(h) for h in halves]
+        if producers is None:
+            state = [(h, None) for h in halves]
+        else:  # each part's input is made on the part's stream (ViT: the patch projection of its images)
+            state = []
+            for k in range(n_parts):
+                with torch.cuda.stream(streams[k]):
+                    state.append((producers[k](), None))
+        oks = [plan(t) for t, _ in state]
         first = [0]
-        for h in halves:
-            first.append(first[-1] + h.shape[0])
+        for t, _ in state:
+            first.append(first[-1] + t.shape[0])
+        # the result is allocated on the caller's stream: every tensor a side stream allocates also dies on it, so the caching
+        # allocator needs no cross-stream bookkeeping (record_stream)
+        out = torch.empty((first[-1],) + tuple(state[0][0].shape[1:]), dtype=state[0][0].dtype, device=device)
+        if any(o != oks[0] for o in oks[1:]):  # (producers only; rare) different paths per part: one piece on the caller's stream
+            for k in range(n_parts):
+                with torch.cuda.stream(streams[k]):
+                    out[first[k] : first[k + 1]].copy_(state[k][0])
+            for st in streams[1:]:
+                cur.wait_stream(st)
+            return self.forward(out)
         for i in range(len(layers)):
-            for k in reversed(range(len(halves))):
+            for k in reversed(range(n_parts)):
                 with torch.cuda.stream(streams[k]):
                     state[k] = step(i, oks[k], state[k][0], state[k][1])
                     if i == len(layers) - 1:
@@ -532,6 +550,15 @@ class Encoder(nn.Sequential):
         for st in streams[1:]:
             cur.wait_stream(st)
         return out
+
+    def split_sizes(self, batch: int, tokens: int, dtype: torch.dtype, device: torch.device):
+        """[(lo, hi), ...] = the batch ranges forward() would run on separate streams for a (batch, tokens, d) input, or None."""
+        want = ENCODER_STREAMS or int(os.environ.get("PM_ENCODER_STREAMS", "0")) or self.pm_streams
+        if want < 2 or device.type != "cuda" or batch < 2 or dtype != torch.bfloat16 or batch * tokens < 32768:
+            return None
+        want = min(want, 4, batch)
+        cuts = [batch * k // want for k in range(want + 1)]
+        return [(cuts[k], cuts[k + 1]) for k in range(want)]
 
     pm_streams = 1  # 2 on instances whose owner opts in (ViT): see _two_streams
 
@@ -542,14 +569,10 @@ class Encoder(nn.Sequential):
         every encoder: with HIP-graph replays queued behind it on the caller's stream - Whisper's decode steps, when the host runs
         ahead of the GPU - the fork's cross-stream wait makes every one of those replays slower (measured: +9 ms per 227-replay
         step against 0.15 ms gained in the encoder; with a host synchronisation per step, or no graphs, it costs nothing)."""
-        want = ENCODER_STREAMS or int(os.environ.get("PM_ENCODER_STREAMS", "0")) or self.pm_streams
-        if want < 2 or not x.is_cuda or x.dim() != 3 or x.shape[0] < 2:
+        if x.dim() != 3:
             return None
-        if x.dtype != torch.bfloat16 or x.shape[0] * x.shape[1] < 32768:
-            return None
-        want = min(want, 4, x.shape[0])
-        cuts = [x.shape[0] * k // want for k in range(want + 1)]
-        return [x[cuts[k] : cuts[k + 1]] for k in range(want)]
+        cuts = self.split_sizes(x.shape[0], x.shape[1], x.dtype, x.device)
+        return None if cuts is None else [x[lo:hi] for lo, hi in cuts]
 
 
 class Decoder(nn.ModuleList):
