@@ -69,6 +69,7 @@ def _f32(module: nn.Module, key: str, t: Tensor | None) -> Tensor | None:
 
 _FLOATS = (torch.bfloat16, torch.float32)
 _SIDE_STREAMS: dict = {}
+_MIN_SPLIT_ROWS = int(os.environ.get("PM_ENCODER_MIN_ROWS", "12288"))  # smallest (batch x tokens) split over two streams: ViT-B/16 gains 5 % at batch 64, 11 % at 128, 6 % at 160, 3-5 % at 256; at batch 32 the doubled launch count makes the host the bottleneck (-39 %)
 ENCODER_STREAMS = 0  # 0 = the instance / PM_ENCODER_STREAMS decide; 1 = one stream (bench.py's per-kernel timing pass sets it); 2 = two
 
 
@@ -554,7 +555,7 @@ class Encoder(nn.Sequential):
     def split_sizes(self, batch: int, tokens: int, dtype: torch.dtype, device: torch.device):
         """[(lo, hi), ...] = the batch ranges forward() would run on separate streams for a (batch, tokens, d) input, or None."""
         want = ENCODER_STREAMS or int(os.environ.get("PM_ENCODER_STREAMS", "0")) or self.pm_streams
-        if want < 2 or device.type != "cuda" or batch < 2 or dtype != torch.bfloat16 or batch * tokens < 32768:
+        if want < 2 or device.type != "cuda" or batch < 2 or dtype != torch.bfloat16 or batch * tokens < _MIN_SPLIT_ROWS:
             return None
         want = min(want, 4, batch)
         cuts = [batch * k // want for k in range(want + 1)]
@@ -564,7 +565,7 @@ class Encoder(nn.Sequential):
 
     def _two_streams(self, x: Tensor):
         """The two halves of a batch that is worth splitting - a 3-D (batch, tokens, d) bf16 input on a HIP device with at least
-        32768 rows, where the persistent GEMM / attention kernels run - or None.  Opt-in per instance (`pm_streams = 2`: ViT sets
+        _MIN_SPLIT_ROWS rows, where the persistent GEMM / attention kernels run - or None.  Opt-in per instance (`pm_streams = 2`: ViT sets
         it; PM_ENCODER_STREAMS=2 sets it everywhere, =1 or the module switch ENCODER_STREAMS = 1 nowhere).  Not the default for
         every encoder: with HIP-graph replays queued behind it on the caller's stream - Whisper's decode steps, when the host runs
         ahead of the GPU - the fork's cross-stream wait makes every one of those replays slower (measured: +9 ms per 227-replay
