@@ -25,6 +25,12 @@ int pm_linear_bf16_wide_launch(const void* x, int64_t ldx, int64_t x_rows_per_ba
                                int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
                                int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, hipStream_t st);
 bool pm_linear_bf16_wide_applies(int64_t M, int64_t N, int64_t K, int act);
+// linear_bf16_tile.hip
+int pm_linear_bf16_tile_launch(int mi, const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
+                               const void* w, int64_t ldw, const float* bias, const void* resid, int64_t ldr,
+                               int64_t resid_period, void* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln,
+                               hipStream_t st);
+bool pm_linear_bf16_tile_applies(int64_t M, int64_t N, int64_t K, int act);
 // linear_bf16_sk.hip
 int pm_linear_bf16_sk_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                              int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
@@ -509,9 +515,9 @@ int launch_act(int act, bool big, dim3 grid, hipStream_t st, const bf16* X, int6
 // beats the best whole-tile kernel by 3 % (QKV at 6.93 rounds stays whole-tile; linear1 at 9.23, out_proj / linear2 at 2.31 move).
 // Hybrid form (linear_bf16_sk.hip, mode 1): the wide kernel's whole tiles + the last round's tiles in two K halves: its cost is
 // the whole rounds + half a round + the hand-off of one partial tile.
-enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3, PM_K_SK = 4, PM_K_HYB = 5 };
+enum { PM_K_SMALL = 1, PM_K_PERSIST = 2, PM_K_WIDE = 3, PM_K_SK = 4, PM_K_HYB = 5, PM_K_TILE4 = 6, PM_K_TILE5 = 7 };
 static int pm_linear_pick_kernel(int64_t M, int64_t N, int64_t K, bool persist_ok, bool wide_ok, bool sk_ok, bool hyb_ok,
-                                 bool has_resid) {
+                                 bool has_resid, bool tile_ok) {
   static const int forced = [] { const char* e = getenv("PM_GEMM_KERNEL"); return e ? atoi(e) : 0; }();  // experiments: 1 .. 5
   // OFF unless PM_GEMM_STREAMK=1: measured on MI355X (tools/sk_check.py, us, whole-tile 256 x 256 kernel -> stream-K): out_proj
   // 96 -> 118, linear2 316 -> 339, linear1 + GELU 335 -> 352, QKV 196 -> 224, 8192^3 851 -> 935.  The balance is real (every
@@ -530,6 +536,9 @@ static int pm_linear_pick_kernel(int64_t M, int64_t N, int64_t K, bool persist_o
   if (forced && forced != PM_K_SK) sk_ok = false;
   if (forced && forced != PM_K_HYB) hyb_ok = false;
   if (forced == PM_K_WIDE && wide_ok) return PM_K_WIDE;
+  if ((forced == PM_K_TILE4 || forced == PM_K_TILE5) && tile_ok) return forced;
+  static const bool use_tile = [] { const char* e = getenv("PM_GEMM_TILE"); return !e || atoi(e) != 0; }();
+  if (!use_tile || forced) tile_ok = false;
   if (forced == PM_K_PERSIST && persist_ok) return PM_K_PERSIST;
   if (forced == PM_K_SMALL) return PM_K_SMALL;
   if (forced == PM_K_PERSIST) wide_ok = false;  // "no wider than": lets a sweep see each kernel's own curve
@@ -545,6 +554,17 @@ static int pm_linear_pick_kernel(int64_t M, int64_t N, int64_t K, bool persist_o
   const double cp = persist_ok ? rounds(tp, 256, 1.0) * 2.0 : 1e30;
   const double cw = wide_ok ? rounds(tw, 256, 1.0) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
   const double csk = sk_ok ? (tw / 256.0 + 0.25 * 768.0 / (double)K) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
+  // (64 MI) x 256 tiles (linear_bf16_tile.hip): MI = 4 replaces the wide kernel wherever both apply
+  const double t5 = (double)((M + 319) / 320) * (double)((N + 255) / 256);
+  const double ct4 = tile_ok ? rounds(tw, 256, 1.0) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
+  // measured (tools/tile_check.py, M = 50432): QKV at 7 rounds of 256-row tiles = 6 rounds of 320-row tiles (7.5 units) in the
+  // same time, 8192^3 806 against 932 us for 4 against 5 units: per unit of work the taller tile runs ~7 % faster (72 KB instead
+  // of 80 KB through the CU's vector-memory path per 320 rows of MFMA work)
+  const double ct5 = tile_ok ? rounds(t5, 256, 1.0) * 5.0 / (1.07 * (has_resid ? 1.1 : 1.25)) : 1e30;
+  if (tile_ok) {
+    const double bt = ct4 <= ct5 ? ct4 : ct5;
+    if (bt <= cp && bt <= cs) return ct4 <= ct5 ? PM_K_TILE4 : PM_K_TILE5;
+  }
   const double best = cw < cp ? (cw < cs ? cw : cs) : (cp < cs ? cp : cs);
   const double chyb = hyb_ok ? ((double)(int64_t)(tw / 256.0) + 0.5 + 0.25 * 768.0 / (double)K) * 4.0 / (has_resid ? 1.1 : 1.25) : 1e30;
   if (csk < 0.97 * best && csk <= chyb) return PM_K_SK;
@@ -586,13 +606,24 @@ static int linear_impl(const void* x, int64_t ldx, int64_t x_rows_per_batch, int
   const bool staged_ok = persist_ok && y_dtype == PM_BF16 && vec_ok && !(resid && resid_dtype == PM_F32);
   const bool hyb_ok = wide_base && ws && ws_bytes >= pm_linear_sk_ws_bytes() && !((uintptr_t)ws & 15) &&
                       pm_linear_bf16_hyb_applies(M, N, K, act) && !(ln.row_out && act != PM_ACT_NONE);
+  // (64 MI) x 256 tiles: LDS-DMA pieces of 8 whole rows off uniform row bases (M % 8 == 0, plain row addressing), epilogue
+  // modes bias / LayerNorm-fold consumer / residual (+ row partials): a consumer with a residual stays on the 256 x 128 kernel
+  const bool tile_ok = wide_base && pm_linear_bf16_tile_applies(M, N, K, act) && M % 8 == 0 && x_rows_per_batch == 0 &&
+                       !(ln.stats && (resid || ln.row_out)) && !(ln.row_out && act != PM_ACT_NONE);
   int kernel;
-  if (want_ln) {  // the LayerNorm fold lives in the persistent kernels' staged epilogues (row partials: 256 x 128 only)
+  if (want_ln) {  // the LayerNorm fold lives in the persistent kernels' epilogues (row partials: the tile and 256 x 128 kernels)
     if (!staged_ok) return PM_EUNSUPPORTED;
-    kernel = pm_linear_pick_kernel(M, N, K, true, wide_ok, sk_ok, hyb_ok, resid != nullptr);
+    kernel = pm_linear_pick_kernel(M, N, K, true, wide_ok, sk_ok, hyb_ok, resid != nullptr, tile_ok);
     if (kernel == PM_K_SMALL) kernel = PM_K_PERSIST;
   } else {
-    kernel = pm_linear_pick_kernel(M, N, K, persist_ok, wide_ok, sk_ok, hyb_ok, resid != nullptr);
+    kernel = pm_linear_pick_kernel(M, N, K, persist_ok, wide_ok, sk_ok, hyb_ok, resid != nullptr, tile_ok);
+  }
+  if (kernel == PM_K_TILE4 || kernel == PM_K_TILE5) {
+    const int rct = pm_linear_bf16_tile_launch(kernel == PM_K_TILE4 ? 4 : 5, x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias,
+                                               resid, ldr, resid_period, y, ldy, M, N, K, act, ln, st0);
+    if (rct != PM_OK) return rct;
+    PM_CHECK_LAUNCH();
+    return PM_OK;
   }
   if (kernel == PM_K_SK || kernel == PM_K_HYB) {
     const int rck = pm_linear_bf16_sk_launch(x, ldx, x_rows_per_batch, x_batch_stride, w, ldw, bias, resid, ldr, resid_period, y,
