@@ -102,13 +102,19 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
     }                                                                                                                \
     char* xs_ = smem + pp_buf * STAGE;                                                                               \
     const uint32_t kb_ = (uint32_t)(pp_kt * (TBK * 2));                                                              \
-    /* swizzle phase of piece i: bit 2 of (first row of the piece) >> 1, i.e. (wave * 4 MI + 4 i) & 4 */             \
-    _Pragma("unroll") for (int i = 0; i < XP; ++i)                                                                   \
-        glds16_aux<PM_GLDS_X_AUX>(xbase[i] + (uint32_t)(xl0 + kb_ + (lsw ^ (uint32_t)(((wave * MI + i) & 1) * 64))), \
-                                  xs_ + (wave * (8 * MI) + i * 8) * 128);                                            \
-    _Pragma("unroll") for (int i = 0; i < WP; ++i)                                                                   \
-        glds16_aux<PM_GLDS_W_AUX>(wbase[i] + (uint32_t)(wl0 + kb_ + (lsw ^ (uint32_t)((i & 1) * 64))),               \
-                                  xs_ + BM * 128 + (wave * 32 + i * 8) * 128);                                       \
+    /* swizzle phase of piece i: bit 2 of (first row of the piece) >> 1, i.e. (wave * 4 MI + 4 i) & 4.  The phase is   \
+       applied per piece from a scalar the compiler cannot hoist (one v_xor per piece, no second pair of lane offsets  \
+       held - and at MI = 5 spilled - across the K loop) */                                                           \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                                 \
+      uint32_t ph_ = (uint32_t)(((wave * MI + i) & 1) * 64);                                                         \
+      asm volatile("" : "+s"(ph_));                                                                                  \
+      glds16_aux<PM_GLDS_X_AUX>(xbase[i] + (uint32_t)(xl0 + kb_ + (lsw ^ ph_)), xs_ + (wave * (8 * MI) + i * 8) * 128); \
+    }                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < WP; ++i) {                                                                 \
+      uint32_t ph_ = (uint32_t)((i & 1) * 64);                                                                       \
+      asm volatile("" : "+s"(ph_));                                                                                  \
+      glds16_aux<PM_GLDS_W_AUX>(wbase[i] + (uint32_t)(wl0 + kb_ + (lsw ^ ph_)), xs_ + BM * 128 + (wave * 32 + i * 8) * 128); \
+    }                                                                                                                \
     ++pp;                                                                                                            \
     pp_buf ^= 1;                                                                                                     \
     if (++pp_kt == nk) { pp_kt = 0; ++pp_tile; }                                                                     \
@@ -129,6 +135,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
   for (int i = 0; i < MI; ++i) lnst[i] = f32x2{0.f, 1.f};
   bf16x4 rv[RES ? RPF + 1 : 1][4];  // residual values of row blocks q .. q + RPF (accumulator layout)
 
+#ifdef PM_TILE_ABLATE_RESID  // experiment only (tools/build_variant.sh): the address arithmetic stays, the load does not
+#define PM_TILE_RESID_LOAD(dst_, ptr_) { asm volatile("" ::"v"(ptr_)); dst_ = bf16x4{}; }
+#else
+#define PM_TILE_RESID_LOAD(dst_, ptr_) dst_ = *(const bf16x4*)(ptr_)
+#endif
   // residual rows of epilogue block q = hf * MI + i (16 tokens x 64 features of this wave): 8 bytes per lane and feature
   // subtile, addressed as uniform 64-bit base + 32-bit lane offset (SGPR pair + one VGPR, no 64-bit vector arithmetic)
 #define PM_TLOAD_RESID(q_, slot_, m0_, n0_, fr_, fq_)                                                                \
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
     _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                               \
       int nn_ = (n0_) + hf_ * 64 + jj * 16 + (fq_) * 4;                                                              \
       nn_ = nn_ < N ? nn_ : N - 4; /* features beyond N are never stored */                                          \
-      rv[slot_][jj] = *(const bf16x4*)(rb_ + (uint32_t)(ro_ + (uint32_t)nn_ * 2));                                   \
+      PM_TILE_RESID_LOAD(rv[slot_][jj], rb_ + (uint32_t)(ro_ + (uint32_t)nn_ * 2));                                  \
     }                                                                                                                \
   }
 
@@ -207,6 +218,16 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 
     // ---------------- tile finished: epilogue (the next tile's first K step is already in flight)
     kt = 0;
+#ifdef PM_TILE_ABLATE_EPI  // experiment only: keep the accumulators live, skip the epilogue
+    {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(acc[j][i]));
+      ++ti;
+      continue;
+    }
+#endif
     int tm, tn;
     ttile_coords(tbase + local + ti * nloc, tiles_m, tiles_n, tm, tn);
     ++ti;
@@ -287,8 +308,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
         for (int p = 0; p < 2; ++p) {
           const bf16x8 ov = *(const bf16x8*)(p ? rd_ptr1 : rd_ptr0);
           char* const yb = (char*)Y + ((int64_t)(m0 + i * 16 + p * 8) * ldy + n0 + hf * 64) * 2;
+#ifdef PM_TILE_ABLATE_STORE  // experiment only
+          asm volatile("" ::"v"(ov), "v"(yb + ylane));
+#else
           if (i * 16 + p * 8 < mleft && n0 + hf * 64 + sch * 8 < N)  // N % 8 == 0 on this path
             store_y((bf16x8*)(yb + ylane), ov);
+#endif
         }
       }
     }
