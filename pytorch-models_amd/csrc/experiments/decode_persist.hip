@@ -24,7 +24,8 @@
 // K/V caches bf16, fixed summation orders (no atomics on data): graph replay == eager == second run, bit for bit.
 #include <mutex>
 
-#include "common.h"
+#include "../common.h"
+#include "../../../include/pm_mi355x_experiments.h"
 
 namespace {
 

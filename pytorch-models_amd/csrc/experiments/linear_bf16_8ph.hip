@@ -17,7 +17,8 @@
 //           8t + 2(p-1), its MFMA segment one later; G1 one later still): before the barrier ending segment 8t+15 every
 //           wave waits until all but its two youngest half-tile pieces have landed (W0, W1, X0 of tile t+2 are needed by
 //           G0's reads in 8t+16), before the barrier ending 8t+16 until X1(t+2) has landed (G1 reads it in 8t+17).
-#include "common.h"
+#include "../common.h"
+#include "../../../include/pm_mi355x_experiments.h"
 
 namespace {
 

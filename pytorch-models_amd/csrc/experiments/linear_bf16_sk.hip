@@ -28,7 +28,8 @@
 // of each row's ROUNDED outputs per 64-feature block) so that out_proj / linear2 of a fold chain can run here.
 #include <cstdlib>
 
-#include "common.h"
+#include "../common.h"
+#include "../../../include/pm_mi355x_experiments.h"
 
 namespace {
 

@@ -31,7 +31,9 @@ int pm_linear_bf16_tile_launch(int mi, const void* x, int64_t ldx, int64_t x_row
                                int64_t resid_period, void* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln,
                                hipStream_t st);
 bool pm_linear_bf16_tile_applies(int64_t M, int64_t N, int64_t K, int act);
-// linear_bf16_sk.hip
+// experiments/linear_bf16_sk.hip: stream-K and hybrid forms (tiles cut along K; opt-in, measured slower or batch-position
+// dependent: DESIGN.md section 8).  Only in `make experiments` builds; the product keeps whole tiles.
+#ifdef PM_EXPERIMENTS
 int pm_linear_bf16_sk_launch(const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride, const void* w,
                              int64_t ldw, const float* bias, const void* resid, int64_t ldr, int64_t resid_period, void* y,
                              int64_t ldy, int64_t M, int64_t N, int64_t K, int act, PmLnFold ln, void* ws, hipStream_t st,
@@ -39,6 +41,15 @@ int pm_linear_bf16_sk_launch(const void* x, int64_t ldx, int64_t x_rows_per_batc
 bool pm_linear_bf16_hyb_applies(int64_t M, int64_t N, int64_t K, int act);
 bool pm_linear_bf16_sk_applies(int64_t M, int64_t N, int64_t K, int act);
 int64_t pm_linear_sk_ws_bytes();
+#else
+static int pm_linear_bf16_sk_launch(const void*, int64_t, int64_t, int64_t, const void*, int64_t, const float*, const void*, int64_t,
+                                    int64_t, void*, int64_t, int64_t, int64_t, int64_t, int, PmLnFold, void*, hipStream_t, int) {
+  return PM_EUNSUPPORTED;
+}
+static bool pm_linear_bf16_hyb_applies(int64_t, int64_t, int64_t, int) { return false; }
+static bool pm_linear_bf16_sk_applies(int64_t, int64_t, int64_t, int) { return false; }
+static int64_t pm_linear_sk_ws_bytes() { return 0; }
+#endif
 
 namespace {
 

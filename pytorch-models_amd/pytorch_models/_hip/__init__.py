@@ -46,13 +46,10 @@ SIGNATURES = {
     "pm_dec_attention": ([_p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _p], c_int),
     "pm_dec_linear_ksplit": ([_p, _l, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _l, _p, _p, _p], c_int),
     "pm_dec_attention_fused": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p], c_int),
-    "pm_dec_attention_fused_v2": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p], c_int),
     "pm_dec_argmax_reduce": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _l, _p], c_int),
     "pm_dec_advance": ([_p, _p], c_int),
     "pm_dec_whisper_rules": ([_p, _l, _l, _p, _l, _p, _l, _l, _l, _l, _l, _p, _l, _p, _l, _l, _p], c_int),
     "pm_dec_sample_topk": ([_p, _l, _l, _l, ctypes.c_uint64, _p, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p], c_int),
-    "pm_dec_layers": ([_p, _l, _l, _l, _l, _l, _l, _l, _i, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p], c_int),
-    "pm_dec_layers_grid": ([], c_int),
     "pm_dec_next_token": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _l, _p], c_int),
     "pm_layernorm": ([_p, _l, _i, _p, _p, _f, _p, _l, _i, _l, _l, _p], c_int),
     "pm_layernorm_ex": ([_p, _l, _i, _p, _p, _f, _i, _p, _l, _i, _p, _l, _i, _l, _l, _p], c_int),
@@ -71,6 +68,14 @@ SIGNATURES = {
     "pm_vit_tokens_generic": ([_p, _p, _l, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p], c_int),
 }
 
+# Entry points of the experiment kernels (include/pm_mi355x_experiments.h; csrc/experiments/): present only in
+# build/libpm_mi355x_exp.so (`make experiments`, loaded through PM_MI355X_LIB).  Bound when the loaded library has them.
+EXPERIMENT_SIGNATURES = {
+    "pm_dec_attention_fused_v2": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p], c_int),
+    "pm_dec_layers": ([_p, _l, _l, _l, _l, _l, _l, _l, _i, _l, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p], c_int),
+    "pm_dec_layers_grid": ([], c_int),
+    "pm_gemm8ph_bench": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _p], c_int),
+}
 
 
 class DecLayer(ctypes.Structure):
@@ -104,10 +109,20 @@ def lib() -> ctypes.CDLL:
             fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = restype
+        for name, (argtypes, restype) in EXPERIMENT_SIGNATURES.items():
+            if hasattr(L, name):
+                fn = getattr(L, name)
+                fn.argtypes = argtypes
+                fn.restype = restype
         if L.pm_abi_version() != 1:
             raise RuntimeError(f"libpm_mi355x ABI {L.pm_abi_version()} != binding ABI 1: rebuild the library")
         _lib = L
     return _lib
+
+
+def has_experiments() -> bool:
+    """True when the loaded library is the experiments build (csrc/experiments/ linked in)."""
+    return hasattr(lib(), "pm_dec_layers")
 
 
 def check(code: int, what: str) -> None:

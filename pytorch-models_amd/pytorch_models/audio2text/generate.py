@@ -90,7 +90,8 @@ class GreedyDecoder:
         hids = {layer.mlp.linear1.out_features for layer in dec.layers}
         persist_ok = (all(layer.pre_norm for layer in dec.layers) and len(acts) == 1 and len(hids) == 1 and d % 64 == 0 and d <= 1280
                       and hid_max % 32 == 0 and ksp_p <= 8 and S <= 2048 and self.Ttot <= 2048 and fused
-                      and len({layer.ca is None for layer in dec.layers}) == 1 and L.pm_dec_layers_grid() > 0)
+                      and len({layer.ca is None for layer in dec.layers}) == 1 and hasattr(L, "pm_dec_layers")
+                      and L.pm_dec_layers_grid() > 0)
         if path == "persistent" and not persist_ok:
             raise NotImplementedError("greedy decode: the persistent layer kernel needs pre-norm layers of one MLP width and activation, "
                                       "d_model % 64 == 0 <= 1280, memory and total length <= 2048")
@@ -101,7 +102,7 @@ class GreedyDecoder:
         persistent = self.path == "persistent"
         table = []
         # the attention block with the whole K stream in flight from the start (decode_persist.hip): opt-in, for A/B runs
-        v2 = os.environ.get("PM_DEC_ATTN_V2", "0") != "0" and max(S, self.Ttot) <= 2048  # measured slower (527 vs 461 us per step): off
+        v2 = os.environ.get("PM_DEC_ATTN_V2", "0") != "0" and max(S, self.Ttot) <= 2048 and hasattr(L, "pm_dec_attention_fused_v2")  # measured slower (527 vs 461 us per step): off
         attn_fused = L.pm_dec_attention_fused_v2 if v2 else L.pm_dec_attention_fused
         self.B, self.P, self.n_steps = B, P, self.Ttot - 1
         Tmax = self.Ttot

@@ -15,6 +15,22 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_hip.SIGNATURES) == declared, "ctypes SIGNATURES table out of sync with the header"
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """exported pm_* == declared: the shipped library carries no undeclared entry point (an experiment's bench export
+    rode along).  The product library is checked against pm_mi355x.h; an experiments build (PM_MI355X_LIB=...libpm_mi355x_exp.so)
+    additionally against pm_mi355x_experiments.h."""
+    import re
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if re.match(r"^[0-9a-f]+ T pm_[a-z0-9_]+$", l.strip())})
+    allowed = set(_hip.header_functions())
+    if os.path.basename(_hip.LIB_PATH) != "libpm_mi355x.so":
+        allowed |= set(_hip.EXPERIMENT_SIGNATURES)
+    extra = [n for n in exported if n not in allowed]
+    assert exported and not extra, f"exported but not declared: {extra}"
+
+
 def test_abi_version_and_error_strings():
     L = _hip.lib()
     assert L.pm_abi_version() == 1

@@ -6,13 +6,20 @@ storage points; plus: hidden state after a step equal to the launch path's to fp
 second run bit for bit (the hand-offs add no order dependence), no hand-off timed out (err word), and the geometry
 corners of the work distribution: ragged 16-row tiles, several row tiles, heads that do not divide the workgroup count,
 decoder-only stacks (no cross block), d_model 384 / 512 / 768 / 1280."""
+import os
+
 import pytest
 import torch
 
 from oracle import ref_whisper as RW
 from synthweights import bf16_round_, fill_module, synth_input, synth_tokens
 
-pytestmark = pytest.mark.gpu
+from pytorch_models import _hip
+
+# an EXPERIMENT (csrc/experiments/decode_persist.hip): runs against build/libpm_mi355x_exp.so (`make experiments`,
+# PM_MI355X_LIB=<that file>); with the product library these tests are skipped
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(_hip.LIB_PATH) or not _hip.has_experiments(),
+                                                  reason="experiments build only (make experiments; PM_MI355X_LIB)")]
 torch.set_grad_enabled(False)
 
 

@@ -16,6 +16,11 @@ from oracle import ref_vit as RV
 from synthweights import synth_input
 
 pytestmark = pytest.mark.gpu
+
+
+def _hip_has_experiments() -> bool:
+    from pytorch_models import _hip
+    return os.path.exists(_hip.LIB_PATH) and _hip.has_experiments()
 torch.set_grad_enabled(False)
 
 
@@ -312,6 +317,24 @@ def test_vit_tokens(ops, N, img, d, cls):
     close_bf16(got, want)
 
 
+@pytest.mark.parametrize("kernel", ["6", "7"])
+def test_tile_gemm_kernels_forced(kernel):
+    """csrc/linear_bf16_tile.hip forced by PM_GEMM_KERNEL: 6 = 256 x 256 tiles, 7 = 320 x 256 tiles, in a fresh process
+    (tools/tile_check.py): ViT-B/16's four GEMMs at batch 256 (bias + residual + LayerNorm-fold row partials from the matrix
+    pipe; LayerNorm-fold consumer with and without GELU), ragged edges (M = 4104 = 16 tiles + 8 rows, N = 520 / 1000: rows and
+    features beyond the operand are loaded clamped and never stored), one tile per workgroup (M = 25216 at 320 rows), the
+    smallest shape the dispatcher sends here; values against an fp32 reference on every 97th row and the last 40, row partials
+    against sums over the rounded outputs, bit-identical reruns."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "tile_check.py")], env=dict(os.environ, PM_GEMM_KERNEL=kernel),
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not _hip_has_experiments(), reason="experiments build only (make experiments; PM_MI355X_LIB)")
 @pytest.mark.parametrize("kernel", ["4", "5"])
 def test_k_split_gemm_matches_whole_tiles(kernel):
     """csrc/linear_bf16_sk.hip, forced by PM_GEMM_KERNEL: 4 = stream-K (opt-in: K steps dealt out as one stream), 5 = the
