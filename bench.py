@@ -1,11 +1,13 @@
 """bench.py - the hot path on N MI355X of one node, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload both|vit|whisper|stub]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload both|vit|whisper|c4|c5|stub]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 BASELINE.json's metric has two halves and the default run times BOTH, each for exactly K steps after W warm-ups:
   vit     : ViT-B/16 bf16 forward, batch 256 per GPU, 224x224 (BASELINE.json configs[1])
   whisper : Whisper-base log-mel + encoder + 224-step KV-cached greedy decode, 32 x 30 s clips per GPU (configs[2])
+  c4      : Whisper large-v2, the same pipeline, 32 clips per GPU = BASELINE configs[3] at --gpus 8 (batch 256 over 8 GPUs)
+  c5      : ViT-L/16 siglip @384 bf16 forward, 256 images per GPU = BASELINE configs[4] at --gpus 8 (batch 2048 over 8 GPUs)
 One "step" = one pass of the hot path over one per-GPU batch of synthetic input already resident in HBM.
 Rank 0 prints ONE JSON line: the top-level metric fields are the ViT-B/16 leg (the configuration the metric is quoted on
 first), the Whisper leg is the "whisper" object and is repeated under config.legs / roofline.whisper / cpu_baseline.whisper.
@@ -32,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM_GBS = 8000.0
-PROFILE_DIRS = ("r02", "r01")  # committed rocprofv3 PMC summaries, newest first
+PROFILE_DIRS = ("r03", "r02", "r01")  # committed rocprofv3 PMC summaries, newest first
 
 
 def host_cores() -> int:
@@ -100,18 +102,28 @@ def timed_steps(step, args, world):
     return time.perf_counter() - t0
 
 
-def run_vit(args, rank, world, device):
+VIT_LEGS = {
+    # tag, image size, per-GPU batch, output width, FLOP per image, BASELINE config
+    "vit": dict(tag="B/16", img=224, batch=256, d=768, flops=None, name="ViT-B/16", cfg="BASELINE configs[1]", traffic="vit_traffic.json"),
+    "c5": dict(tag="L/16_siglip", img=384, batch=256, d=1024, flops=383.9e9, name="ViT-L/16 siglip @384",
+               cfg="BASELINE configs[4]: batch 2048 over 8 GPUs = 256 per GPU", traffic="c5_traffic.json"),
+}
+
+
+def run_vit(args, rank, world, device, leg="vit"):
     from pytorch_models import dp
     from pytorch_models._hip import ops
     from pytorch_models.image import ViT
     from synthweights import fill_module, synth_input
 
-    B = args.batch or 256
-    m = ViT.from_google("B/16").eval()
+    L = VIT_LEGS[leg]
+    B = args.batch or L["batch"]
+    m = (ViT.from_google(L["tag"]) if L["img"] == 224 else ViT.from_google(L["tag"], img_size=L["img"])).eval()
     fill_module(m, 32)
     m = m.to(torch.bfloat16).to(device)
-    imgs = synth_input(f"vit_bench_r{rank}", (B, 3, 224, 224), 100 + rank).to(device)
-    gather = dp.OutputGatherer(B * world, (768,), torch.bfloat16, device) if world > 1 else None
+    imgs = synth_input(f"{leg}_bench_r{rank}", (B, 3, L["img"], L["img"]), 100 + rank).to(device)
+    gather = dp.OutputGatherer(B * world, (L["d"],), torch.bfloat16, device) if world > 1 else None
+    flops_img = L["flops"] or vit_flops_per_image()
 
     def step():
         out = m(imgs)
@@ -141,11 +153,11 @@ def run_vit(args, rank, world, device):
         sync(world)
     dt = max_over_ranks(dt, world, device)
     res = {
-        "metric": "ViT-B/16 images/s",
+        "metric": f"{L['name']} images/s",
         "value": round(world * B * args.steps / dt, 1),
         "unit": "images/s",
         "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "config": {"workload": f"ViT-B/16 bf16 forward, batch={B} per GPU, 224x224 (BASELINE configs[1])",
+        "config": {"workload": f"{L['name']} bf16 forward, batch={B} per GPU, {L['img']}x{L['img']} ({L['cfg']})",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "collective": "dp.OutputGatherer: all_gather_into_tensor(outputs)" if world > 1 else "none"},
         "dtype": "bf16",
@@ -155,19 +167,29 @@ def run_vit(args, rank, world, device):
         kern = summarize_launches(log)
         lin = kern["linear_bf16"]
         ach = lin["work"] / lin["ms"] / 1e9  # flop / ms -> TFLOP/s
-        traffic, tfile = measured_traffic("vit_traffic.json")
-        res["roofline"] = {"bound": "mfma", "kernel": "linear_bf16 kernels (QKV, out_proj, fc1 + GELU, fc2 of 12 layers)",
+        traffic, tfile = measured_traffic(L["traffic"])
+        n_layers = len(m.layers)
+        lin_flops_step = lin["work"] / args.steps
+        res["roofline"] = {"bound": "mfma", "kernel": f"linear_bf16 kernels (QKV, out_proj, fc1 + GELU, fc2 of {n_layers or 'all'} layers)",
                            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                            "traffic_unit": f"bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, {tfile})",
                            "algorithmic_bytes_per_launch": round(lin["bytes"] / lin["n"]) if lin.get("bytes") else None,
                            "launches": lin["n"], "avg_launch_us": round(1e3 * lin["ms"] / lin["n"], 2),
-                           "note": "per-kernel HIP-event timing of K extra steps with the encoder on one stream (full-M launches, "
-                                   "no overlap: rocprofv3 summary of `PM_ENCODER_STREAMS=1 python bench.py` = "
-                                   "profiles/r02/bench_one_stream_kernel_stats.csv); the timed region runs the product default - the "
-                                   "two halves of the batch on two streams (profiles/r02/bench_both_legs_kernel_stats.csv)"}
+                           # the timed region (product default: two halves of the batch on two streams) cannot be bracketed per
+                           # kernel - concurrent kernels overlap -; what it does give: the linear kernels' flops over the WHOLE
+                           # step time, a lower bound of their aggregate rate there (attention, patch embedding and the small
+                           # kernels are inside that time too)
+                           "default_schedule": {"streams": 2, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                                                "linear_tflop_per_step": round(lin_flops_step / 1e12, 3),
+                                                "linear_tflops_over_whole_step": round(lin_flops_step / (dt / args.steps) / 1e12, 1),
+                                                "frac_lower_bound": round(lin_flops_step / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)},
+                           "note": "achieved / avg_launch_us: per-kernel HIP-event timing of K extra steps with the encoder on ONE "
+                                   "stream (full-M launches, no overlap; rocprofv3 --kernel-trace --stats of `PM_ENCODER_STREAMS=1 "
+                                   f"python bench.py --workload {leg}` = profiles/r03/bench_{leg}_one_stream_kernel_stats.csv; of the "
+                                   f"default two-stream run = profiles/r03/bench_{leg}_default_kernel_stats.csv)"}
         res["kernels"] = {k: {"launches": v["n"], "total_ms": round(v["ms"], 3)} for k, v in kern.items()}
-        res["model_tflops"] = round(vit_flops_per_image() * B * args.steps / dt / 1e12, 1)
+        res["model_tflops"] = round(flops_img * B * args.steps / dt / 1e12, 1)
         res["model_frac_of_peak"] = round(res["model_tflops"] / PEAK_BF16_TFLOPS, 4)
     return res
 
@@ -242,7 +264,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="both", choices=["both", "vit", "whisper", "stub"])
+    ap.add_argument("--workload", default="both", choices=["both", "vit", "whisper", "c4", "c5", "stub"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the BASELINE config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--whisper-layers", type=int, default=0,
@@ -287,10 +309,13 @@ def main():
         legs["stub"] = run_stub(args, rank, world, device)
     if args.workload in ("both", "vit"):
         legs["vit"] = run_vit(args, rank, world, device)
-    if args.workload in ("both", "whisper"):
+    if args.workload == "c5":
+        legs["c5"] = run_vit(args, rank, world, device, "c5")
+    if args.workload in ("both", "whisper", "c4"):
         from bench_whisper import run_whisper
 
-        legs["whisper"] = run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, timed_steps)
+        wleg = "c4" if args.workload == "c4" else "whisper"
+        legs[wleg] = run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, timed_steps, leg=wleg)
 
     if rank == 0:
         want_cpu = not args.no_cpu_baseline and world == 1  # rank 0, N = 1 only

@@ -306,6 +306,14 @@ int pm_dec_attention_fused(const float* x, int64_t d, const float* gamma, const 
                            const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, float* out, int64_t B, int64_t H,
                            int self_attn, void* stream);
 
+/* pm_dec_attention_fused with FLOAT K / V caches (kc, vc point to f32, strides in elements): nothing is rounded when a key
+ * or value is cached - the reference-accuracy decode of Whisper.generate(exact=True), captured in the same step graph as the
+ * bf16-cache path (text/generator.py:23-35 semantics, fp32 throughout).  Same arguments otherwise. */
+int pm_dec_attention_fused_kv32(const float* x, int64_t d, const float* gamma, const float* beta, float eps, const void* w,
+                                const float* bias, void* kc, void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
+                                const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, float* out, int64_t B, int64_t H,
+                                int self_attn, void* stream);
+
 /* Finish the argmax over the n_tiles tile winners of pm_dec_linear mode 2 (lowest index on ties, like torch.argmax),
  * teacher-force the prompt (next = prompt[b, t+1] while t + 1 < P), write tok_cur[b] and tokens_out[b, t+1]. */
 int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_tiles, const int32_t* pos_ptr,

@@ -711,12 +711,20 @@ __device__ __forceinline__ float block_reduce8(float v, float* slot, bool is_max
   return r;
 }
 
-template <bool SELF, int NCH>
+// KT = the element type of the K / V caches: bf16 (the throughput path: k, v rounded once when cached) or float (the
+// reference-accuracy path, Whisper.generate(exact=True): nothing is rounded anywhere, twice the bytes per key).
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+template <typename KT> struct KV8;
+template <> struct KV8<bf16> { typedef bf16x8 type; };
+template <> struct KV8<float> { typedef f32x8 type; };
+
+template <bool SELF, int NCH, typename KT>
 __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     const float* __restrict__ x, int d, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const bf16* __restrict__ Wp, const float* __restrict__ bp,  // SELF: packed [q|k|v] (3*inner, d); cross: q (inner, d)
-    bf16* Kc, bf16* Vc, int64_t sb, int64_t sh, int64_t sk, const int* __restrict__ pos_ptr, int lk_const,
+    KT* Kc, KT* Vc, int64_t sb, int64_t sh, int64_t sk, const int* __restrict__ pos_ptr, int lk_const,
     float* __restrict__ out, int H) {
+  typedef typename KV8<KT>::type kv8;
   __shared__ float sc[DA_MAXK];
   __shared__ float xn[1280];
   __shared__ float qkv[192];
@@ -765,15 +773,15 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   // weights are not queued behind it - and let HBM stream while the LayerNorm and the projection run.
   constexpr int NKU = SELF ? 4 : PM_CROSS_NKU;
   const int c = lane & 7, ks = lane >> 3;
-  const bf16* kb = Kc + b * sb + h * sh + c * 8;
-  const bf16* vb = Vc + b * sb + h * sh + c * 8;
+  const KT* kb = Kc + b * sb + h * sh + c * 8;
+  const KT* vb = Vc + b * sb + h * sh + c * 8;
   const int Lc = SELF ? Lk - 1 : Lk;  // keys read from memory (self: the newest one comes from LDS)
-  bf16x8 kv[NKU];
+  kv8 kv[NKU];
 #pragma unroll
   for (int u = 0; u < NKU; ++u) {
     int key = u * 64 + wave * 8 + ks;
     key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-    kv[u] = SELF ? *(const bf16x8*)(kb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(kb + key * sk));
+    kv[u] = SELF ? *(const kv8*)(kb + key * sk) : __builtin_nontemporal_load((const kv8*)(kb + key * sk));
   }
   // ---- LayerNorm of row b (two-pass from registers)
   float s = 0.f;
@@ -815,8 +823,8 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     acc += __shfl_xor(acc, 4, 64);
     if (pl == 0) {
       float v = acc + bpe[o];
-      if (SELF && o > 0) {  // cached k / v are bf16: round once, store, and use the rounded value for this step too
-        const bf16 r = (bf16)v;
+      if (SELF && o > 0) {  // cached k / v: round once to the cache's type (bf16; float = no rounding), store, use the stored value
+        const KT r = (KT)v;
         (o == 1 ? Kc : Vc)[b * sb + h * sh + (int64_t)tpos * sk + prow] = r;
         v = (float)r;
       }
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       for (int u = 0; u < NKU; ++u) {
         int key = k0 + u * 64 + wave * 8 + ks;
         key = key < Lc ? key : Lc - 1;
-        kv[u] = SELF ? *(const bf16x8*)(kb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(kb + key * sk));
+        kv[u] = SELF ? *(const kv8*)(kb + key * sk) : __builtin_nontemporal_load((const kv8*)(kb + key * sk));
       }
     }
 #pragma unroll
@@ -862,12 +870,12 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     if (c == 0) sc[Lk - 1] = sv * 0.125f;
   }
   // V does not depend on the scores: request the first NKU passes now, so they fly during the softmax reductions
-  bf16x8 vv[NKU];
+  kv8 vv[NKU];
 #pragma unroll
   for (int u = 0; u < NKU; ++u) {
     int key = u * 64 + wave * 8 + ks;
     key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-    vv[u] = SELF ? *(const bf16x8*)(vb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(vb + key * sk));
+    vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
   }
   __syncthreads();
   float mx = -INFINITY;
@@ -891,7 +899,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       for (int u = 0; u < NKU; ++u) {
         int key = k0 + u * 64 + wave * 8 + ks;
         key = key < Lc ? key : Lc - 1;
-        vv[u] = SELF ? *(const bf16x8*)(vb + key * sk) : __builtin_nontemporal_load((const bf16x8*)(vb + key * sk));
+        vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
       }
     }
 #pragma unroll
@@ -1379,10 +1387,11 @@ extern "C" int pm_dec_attention(const float* q, const void* kc, const void* vc, 
   return PM_OK;
 }
 
-extern "C" int pm_dec_attention_fused(const float* x, int64_t d, const float* gamma, const float* beta, float eps,
-                                      const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
-                                      int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
-                                      int64_t lk_max, float* out, int64_t B, int64_t H, int self_attn, void* stream) {
+template <typename KT>
+static int dec_attention_fused_impl(const float* x, int64_t d, const float* gamma, const float* beta, float eps, const void* w,
+                                    const float* bias, void* kc, void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
+                                    const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, float* out, int64_t B, int64_t H,
+                                    int self_attn, void* stream) {
   if (!x || !gamma || !beta || !w || !kc || !vc || !out || B <= 0 || H <= 0 || d <= 0 || lk_max <= 0) return PM_EINVAL;
   if (d % 64 || d > 1280 || lk_max > DA_MAXK) return PM_EUNSUPPORTED;
   if (self_attn ? !pos_ptr : lk_const <= 0) return PM_EINVAL;
@@ -1392,8 +1401,8 @@ extern "C" int pm_dec_attention_fused(const float* x, int64_t d, const float* ga
   hipStream_t st = (hipStream_t)stream;
   const int nch = (int)(d / 64);
 #define PM_DF(SELF_, NCH_)                                                                                            \
-  hipLaunchKernelGGL((dec_attn_fused_kernel<SELF_, NCH_>), dim3((unsigned)(B * H)), dim3(DF_THREADS), 0, st, x, (int)d,   \
-                     gamma, beta, eps, (const bf16*)w, bias, (bf16*)kc, (bf16*)vc, stride_b, stride_h, stride_k,          \
+  hipLaunchKernelGGL((dec_attn_fused_kernel<SELF_, NCH_, KT>), dim3((unsigned)(B * H)), dim3(DF_THREADS), 0, st, x, (int)d, \
+                     gamma, beta, eps, (const bf16*)w, bias, (KT*)kc, (KT*)vc, stride_b, stride_h, stride_k,              \
                      (const int*)pos_ptr, (int)lk_const, out, (int)H)
   if (self_attn) {
     if (nch <= 8) PM_DF(true, 8);
@@ -1409,6 +1418,22 @@ extern "C" int pm_dec_attention_fused(const float* x, int64_t d, const float* ga
 #undef PM_DF
   PM_CHECK_LAUNCH();
   return PM_OK;
+}
+
+extern "C" int pm_dec_attention_fused(const float* x, int64_t d, const float* gamma, const float* beta, float eps,
+                                      const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
+                                      int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
+                                      int64_t lk_max, float* out, int64_t B, int64_t H, int self_attn, void* stream) {
+  return dec_attention_fused_impl<bf16>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr, lk_const,
+                                        lk_max, out, B, H, self_attn, stream);
+}
+
+extern "C" int pm_dec_attention_fused_kv32(const float* x, int64_t d, const float* gamma, const float* beta, float eps,
+                                           const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
+                                           int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
+                                           int64_t lk_max, float* out, int64_t B, int64_t H, int self_attn, void* stream) {
+  return dec_attention_fused_impl<float>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr, lk_const,
+                                         lk_max, out, B, H, self_attn, stream);
 }
 
 extern "C" int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_tiles, const int32_t* pos_ptr,

@@ -48,7 +48,10 @@ class GreedyDecoder:
     """State + launch list of the decode step for one (decoder, batch, memory length) geometry."""
 
     def __init__(self, dec, memory: Tensor, prompt: Tensor, n_new: int, margins: bool = False, fused: bool = True,
-                 topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None, path: str = "auto") -> None:
+                 topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None, path: str = "auto", kv32: bool = False) -> None:
+        """``kv32``: the reference-accuracy form of the same step - fp32 memory in, cross and self K/V kept in fp32 (nothing is
+        rounded when it is cached; pm_dec_attention_fused_kv32), everything else as in the throughput path, whose projections
+        are fp32-exact already (bf16 weights x activations split into three bf16 terms) - graph-replayed like it."""
         if path not in ("auto", "launches", "persistent"):
             raise ValueError("greedy decode: path must be 'auto', 'launches' or 'persistent'")
         E = dec.token_embs.weight
@@ -57,8 +60,8 @@ class GreedyDecoder:
         if memory is None:  # decoder-only language model (GPT-2): no cross-attention, nothing to attend to but itself
             B, S, d = prompt.shape[0], 0, E.shape[1]
         else:
-            if memory.dtype != torch.bfloat16 or memory.dim() != 3:
-                raise ValueError("greedy decode: memory must be the encoder's bf16 (B, S, d) output")
+            if memory.dtype != (torch.float32 if kv32 else torch.bfloat16) or memory.dim() != 3:
+                raise ValueError("greedy decode: memory must be the encoder's (B, S, d) output, bf16 (fp32 with kv32=True)")
             B, S, d = memory.shape
         P = prompt.shape[1]
         if prompt.shape[0] != B or prompt.dtype != torch.int64 or P < 1:
@@ -104,6 +107,12 @@ class GreedyDecoder:
         # the attention block with the whole K stream in flight from the start (decode_persist.hip): opt-in, for A/B runs
         v2 = os.environ.get("PM_DEC_ATTN_V2", "0") != "0" and max(S, self.Ttot) <= 2048 and hasattr(L, "pm_dec_attention_fused_v2")  # measured slower (527 vs 461 us per step): off
         attn_fused = L.pm_dec_attention_fused_v2 if v2 else L.pm_dec_attention_fused
+        self.kv32 = bool(kv32)
+        kv_dt, kv_sz = (torch.float32, 4) if kv32 else (torch.bfloat16, 2)
+        if kv32:
+            if persistent or not fused or B * H > 256 or os.environ.get("PM_DEC_FUSE_SELF") == "0" or os.environ.get("PM_DEC_FUSE_CROSS") == "0":
+                raise NotImplementedError("greedy decode: fp32 K/V caches run on the fused attention blocks (B * n_heads <= 256)")
+            attn_fused = L.pm_dec_attention_fused_kv32
         self.B, self.P, self.n_steps = B, P, self.Ttot - 1
         Tmax = self.Ttot
         f32 = dict(dtype=torch.float32, device=dev)
@@ -170,7 +179,7 @@ class GreedyDecoder:
             if (layer.ca is None) != (memory is None):
                 raise ValueError("greedy decode: cross-attention layers need a memory, decoder-only layers must not get one")
             sa, ca, mlp = layer.sa, layer.ca, layer.mlp
-            kc = torch.empty(B, H, Tmax, 64, dtype=torch.bfloat16, device=dev)
+            kc = torch.empty(B, H, Tmax, 64, dtype=kv_dt, device=dev)
             vc = torch.empty_like(kc)
             self.self_k.append(kc)
             self.self_v.append(vc)
@@ -205,7 +214,7 @@ class GreedyDecoder:
                 # cross attention: K/V of the memory projected ONCE (the reference re-projects them on every call,
                 # transformer.py:44-49), kept packed (B, S, [k | v]) in bf16
                 wkv, bkv = ca._pack("kv")
-                kv = ops.linear(mem2, wkv, bkv)
+                kv = self._project_memory(mem2, wkv, bkv)
                 self.cross_kv.append(kv)
                 self._cross_w.append((wkv, bkv))
                 g, b = _f32(layer.ca_norm, "g", layer.ca_norm.weight), _f32(layer.ca_norm, "b", layer.ca_norm.bias)
@@ -219,7 +228,7 @@ class GreedyDecoder:
                     ent.w_co, ent.b_co = ca.out_proj.weight.data_ptr(), _ptr(bo)
                 elif fuse_cross:
                     add(attn_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
-                        ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
+                        ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * kv_sz, S * 2 * inner, 64,
                         2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
                 else:
                     dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, bq, None, self.q, inner)
@@ -296,17 +305,27 @@ class GreedyDecoder:
                 self.pos.data_ptr(), self.prompt.data_ptr(), P, self.tok_cur.data_ptr(), self.tokens.data_ptr(), self.Ttot,
                 E.data_ptr(), pos_f32.data_ptr(), self.x.data_ptr(), d, self.ticket.data_ptr(), B, None)
 
+    def _project_memory(self, mem2: Tensor, wkv: Tensor, bkv, out: Tensor | None = None) -> Tensor:
+        """packed cross K/V of the memory rows: bf16 GEMM, or (kv32) the exact fp32 product of the fp32 memory with the
+        bf16-valued weights."""
+        if not self.kv32:
+            return ops.linear(mem2, wkv, bkv, out=out)
+        from ..transformer import derived
+
+        w32 = derived(self, ("kv32w", wkv.data_ptr()), (wkv,), lambda: wkv.float())
+        return ops.linear_f32(mem2, w32, bkv, out=out)
+
     def rebind(self, memory: Tensor, prompt: Tensor) -> None:
         """New clips, same geometry: re-project the cross K/V INTO the existing buffers and swap the prompt, so the
         captured graph (which holds raw pointers) stays valid."""
         assert (self.B, self.P) == tuple(prompt.shape)
         if memory is not None:
             B, S, d = memory.shape
-            assert B == self.B and memory.dtype == torch.bfloat16
+            assert B == self.B and memory.dtype == (torch.float32 if self.kv32 else torch.bfloat16)
             mem2 = memory.reshape(B * S, d)
             for kv, (wkv, bkv) in zip(self.cross_kv, self._cross_w):
                 assert kv.shape[0] == B * S
-                ops.linear(mem2, wkv, bkv, out=kv)
+                self._project_memory(mem2, wkv, bkv, out=kv)
         self.prompt.copy_(prompt)
         self.tokens[:, : self.P] = self.prompt
 
@@ -365,12 +384,13 @@ class GreedyDecoder:
 
 @torch.no_grad()
 def greedy_decode(dec, memory: Tensor, prompt: Tensor, n_new: int, *, graph: bool = True, margins: bool = False,
-                  fused: bool = True, topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None, path: str = "auto"):
+                  fused: bool = True, topk: int = 1, seed: int = 0, rules: "WhisperRules | None" = None, path: str = "auto",
+                  kv32: bool = False):
     """tokens (B, P + n_new) int64 [and per-position diagnostic margins].  fused=False uses the unfused
     projection + attention launches (same arithmetic, 2 more launches per layer); topk > 1 samples each token from the
     softmax over the k largest logits on the device (same seed -> same ids); path: "persistent" (all layers of a step in
     one launch), "launches" (a launch per stage) or "auto"."""
-    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused, topk, seed, rules, path)
+    st = GreedyDecoder(dec, memory, prompt, n_new, margins, fused, topk, seed, rules, path, kv32)
     toks = st.run(graph)
     st.check()
     return (toks, st.margins) if margins else toks

@@ -145,7 +145,17 @@ class Whisper(nn.Module):
         bit (tests/test_hip_exact.py); costs ~10x the bf16 encoder and an eager fp32 step loop.  A model whose
         parameters are fp32 always decodes this way."""
         if exact and self.decoder.token_embs.weight.dtype != torch.float32:
-            return self.exact_copy().generate(x, prompt, max_new_tokens)
+            # fp32 encoder on the fp32 twin of the (bf16-valued) weights; the decode step is the throughput path's own launch
+            # list with fp32 K / V caches - its projections are fp32-exact as they stand (bf16 weights x activations in three
+            # bf16 terms) - replayed as one HIP graph per token.  Geometries that list does not cover (more than 256
+            # (sequence, head) pairs) fall back to the eager fp32 loop of the twin.
+            from .generate import greedy_decode
+
+            twin = self.exact_copy()
+            H = self.decoder.layers[0].sa.n_heads
+            if rules is None and prompt.shape[0] * H <= 256 and prompt.shape[0] <= 64:
+                return greedy_decode(self.decoder, twin.encoder(x), prompt, max_new_tokens, graph=graph, kv32=True)
+            return twin.generate(x, prompt, max_new_tokens)
         return self.decoder.generate(self.encoder(x), prompt, max_new_tokens, graph=graph, rules=rules, path=path)
 
     def exact_copy(self) -> "Whisper":
