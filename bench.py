@@ -267,6 +267,7 @@ def main():
     ap.add_argument("--workload", default="both", choices=["both", "vit", "whisper", "c4", "c5", "stub"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = the BASELINE config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="whisper: skip the labelled exact-mode extra (generate(exact=True))")
     ap.add_argument("--whisper-layers", type=int, default=0,
                     help="whisper: layers per stack (0 = 8, the reference's \"base\"; 6 = OpenAI's base geometry, a labelled extra: SURVEY.md F2)")
     ap.add_argument("--backend", default="nccl", help='torch.distributed backend ("nccl" = RCCL; "gloo" only to rehearse N > 1 on one GPU or on CPU)')
@@ -321,7 +322,7 @@ def main():
         want_cpu = not args.no_cpu_baseline and world == 1  # rank 0, N = 1 only
         if want_cpu and "vit" in legs:
             legs["vit"]["cpu_baseline"] = cpu_baseline_vit()
-        if want_cpu and "whisper" in legs and legs["whisper"]["_layers"] == 8:  # the CPU leg is the BASELINE geometry's
+        if want_cpu and "whisper" in legs and legs["whisper"]["_layers"] == 8 and "large" not in legs["whisper"]["metric"]:  # the CPU leg is the BASELINE geometry's
             from bench_whisper import cpu_baseline_whisper
 
             legs["whisper"].update(cpu_baseline_whisper(host_cores()))

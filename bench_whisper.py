@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 def _traffic(name):
     import json
 
-    for r in ("r02", "r01"):
+    for r in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", r, name)
         if os.path.exists(path):
             return round(json.load(open(path))["traffic_bytes_per_launch"]), f"profiles/{r}/{name}"
@@ -66,20 +66,54 @@ def cpu_baseline_whisper(cores: int) -> dict:
     }
 
 
-def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, timed_steps):
+WHISPER_LEGS = {
+    # model tag, per-GPU batch, metric name, BASELINE config
+    "whisper": dict(tag="base", batch=32, name="Whisper-base", cfg="BASELINE configs[2]", traffic="whisper_step_traffic.json"),
+    "c4": dict(tag="large-v2", batch=32, name="Whisper-large-v2", cfg="BASELINE configs[3]: batch 256 over 8 GPUs = 32 clips per GPU",
+               traffic="c4_step_traffic.json"),
+}
+
+
+def exact_extra(m, pre, wave, prompt, fast_ids, ms_default):
+    """Labelled extra of the Whisper-base leg: the reference-accuracy mode, generate(exact=True) - fp32 encoder on the fp32 twin of
+    the bf16-valued weights, fp32 cross / self K/V in the graph-replayed step - timed once on the same clips.  Its ids are the
+    reference's fp32 forward's on the same weights (tests/test_hip_exact.py pins that against the reference's own 224-token
+    goldens, bit for bit); here: how much it costs and how far the default mode's ids are from it."""
+    mel = pre(wave)
+    ids = m.generate(mel, prompt, N_NEW, exact=True)  # builds the twin, captures the step graph
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids = m.generate(pre(wave), prompt, N_NEW, exact=True)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    B = wave.shape[0]
+    again = m.generate(pre(wave), prompt, N_NEW, exact=True)
+    return {"mode": "Whisper.generate(exact=True): fp32 encoder + fp32 K/V decode (same step kernels, one graph replay per token)",
+            "value": round(B * 30.0 / (ms / 1e3), 1), "unit": "audio-s/s", "ms_per_step": round(ms, 2),
+            "times_default_step": round(ms / ms_default, 2),
+            "ids_equal_reference_semantics": "bit-exact vs the reference's fp32 greedy loop on the same bf16-valued weights: pinned by "
+                                             "tests/test_hip_exact.py::test_exact_mode_of_the_bf16_model_equals_the_reference_bit_for_bit "
+                                             "(tiny and base goldens, 2 x 228 ids each)",
+            "rerun_identical": bool(torch.equal(ids, again)),
+            "default_mode_agrees_on": round((fast_ids == ids).float().mean().item(), 4)}
+
+
+def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launches, timed_steps, leg="whisper"):
     from pytorch_models import dp
     from pytorch_models._hip import ops
     from pytorch_models.audio2text import Whisper, WhisperPreprocessor
     from pytorch_models.audio2text.generate import GreedyDecoder
     from synthweights import fill_module, synth_input, synth_tokens
 
-    B = args.batch or 32
-    tag = "base"
-    m = Whisper.from_openai(tag).eval()  # 8 layers, exactly as the reference builds "base" 
+    LEG = WHISPER_LEGS[leg]
+    B = args.batch or LEG["batch"]
+    tag = LEG["tag"]
+    m = Whisper.from_openai(tag).eval()  # "base": 8 layers, exactly as the reference builds it (SURVEY.md F2)
     n_layers = len(m.encoder.layers)
     if getattr(args, "whisper_layers", 0) and args.whisper_layers != n_layers:  # labelled extra, not the BASELINE config
         n_layers = args.whisper_layers
         m = Whisper(51865, n_layers, 512).eval()
+    d_model = m.decoder.token_embs.weight.shape[1]
     fill_module(m, 56)
     m = m.to(torch.bfloat16).to(device)
     pre = WhisperPreprocessor(tag).to(device)
@@ -127,13 +161,13 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
         sync(world)
     dt = max_over_ranks(dt, world, device)
     res = {
-        "metric": "Whisper-base audio-sec/s",
+        "metric": f"{LEG['name']} audio-sec/s",
         "value": round(world * B * 30.0 * args.steps / dt, 1),
         "unit": "audio-s/s",
         "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "config": {"workload": f"Whisper-base ({'reference geometry: 8' if n_layers == 8 else 'EXTRA, not the BASELINE config: ' + str(n_layers)} layers, d=512): log-mel + encoder + greedy decode "
+        "config": {"workload": f"{LEG['name']} ({('reference geometry: ' if leg == 'c4' or n_layers == 8 else 'EXTRA, not the BASELINE config: ') + str(n_layers)} layers, d={d_model}): log-mel + encoder + greedy decode "
                                f"(prompt {PROMPT}, {N_NEW} new tokens, KV cache), 30 s synthetic audio, batch={B} per GPU "
-                               "(BASELINE configs[2])",
+                               f"({LEG['cfg']})",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "decode_path": getattr(dec, "path", "launches"),
                    "collective": "dp.OutputGatherer: all_gather_into_tensor(token ids)" if world > 1 else "none"},
@@ -149,7 +183,7 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
         step_bytes = decode_step_bytes(B, d, n_layers, V, S, PROMPT, N_NEW)
         us_step = 1e3 * t_decode / dec.n_steps
         ach = step_bytes / us_step / 1e3  # bytes / us -> GB/s
-        traffic, tfile = _traffic("whisper_step_traffic.json")
+        traffic, tfile = _traffic(LEG["traffic"])
         res["roofline"] = {
             "bound": "hbm", "kernel": f"whole decode step ({getattr(dec, 'path', 'launches')}: {len(dec.launches)} launches per step, one graph replay)",
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
@@ -176,9 +210,12 @@ def run_whisper(args, rank, world, device, sync, max_over_ranks, summarize_launc
             cross_ms = sum(a.elapsed_time(b) for a, b in cross)
             cross_bytes = 2 * B * S * d * 2 + 2 * B * d * 4 + d * d * 2  # packed cross K/V (bf16) + x, out (f32) + the q weight once
             c_ach = len(cross) * cross_bytes / cross_ms / 1e6
-            ctraffic, cfile = _traffic("whisper_traffic.json")
+            ctraffic, cfile = _traffic("whisper_traffic.json" if leg == "whisper" else "c4_traffic.json")
             res["roofline"]["dominant_kernel"] = {
                 "kernel": "dec_attn_fused_kernel<false> (LN + q-proj + cross-attention over 1500 keys)", "achieved": round(c_ach, 1),
                 "unit": "GB/s", "frac": round(c_ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": cross_bytes,
                 "traffic": ctraffic, "traffic_file": cfile, "avg_launch_us": round(1e3 * cross_ms / len(cross), 2), "launches": len(cross)}
+        if leg == "whisper" and n_layers == 8 and world == 1 and not getattr(args, "no_exact", False):
+            with torch.no_grad():
+                res["exact"] = exact_extra(m, pre, wave, prompt, dec.run(graph=use_graph).clone(), res["ms_per_step"])
     return res
