@@ -12,6 +12,7 @@ import math
 import torch
 from torch import Tensor, nn
 
+from .. import _cpu
 from .._hip import ops
 from ..transformer import derived
 
@@ -46,6 +47,8 @@ class Spectrogram(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         """(..., T) -> (..., n_fft/2+1, 1 + T // hop) power spectrogram (center=True, reflect padding)."""
+        if _cpu.on_cpu(x, self.window):
+            return _cpu.spectrogram(x, self.window, self.n_fft, self.hop_length)
         return ops.stft_mel(x, self._tables(), self.n_fft, self.hop_length, 1 + x.shape[-1] // self.hop_length, 0)
 
 
@@ -59,5 +62,7 @@ class MelSpectrogram(Spectrogram):
         return derived(self, "csr", (self.filters,), lambda: ops.mel_csr(self.filters))
 
     def forward(self, x: Tensor) -> Tensor:
+        if _cpu.on_cpu(x, self.window, self.filters):
+            return _cpu.mel_spectrogram(x, self.window, self.filters, self.n_fft, self.hop_length)
         return ops.stft_mel(x, self._tables(), self.n_fft, self.hop_length, 1 + x.shape[-1] // self.hop_length, 1,
                             self._csr(), self.filters.shape[0])

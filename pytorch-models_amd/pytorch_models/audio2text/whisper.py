@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor, nn
 
+from .. import _cpu
 from .._hip import ops
 from ..audio.spectrogram import MelSpectrogram
 from ..transformer import Decoder, Encoder, LayerNorm, _f32, _wb, derived
@@ -53,6 +54,8 @@ class WhisperEncoder(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         """(B, n_mels, T) -> (B, T // 2, d): conv stem (both convs as MFMA GEMMs with fused GELU, the second
         also adding pos_embs in its epilogue), Encoder, LayerNorm."""
+        if _cpu.on_cpu(x, self.stem[0].weight):  # CPU tensors and parameters: plain torch (pytorch_models/_cpu.py)
+            return self.norm(self.layers(_cpu.whisper_stem(self, x)))
         if self.stem[0].weight.dtype == torch.float32:
             return self._forward_f32(x)
         w1, b1, w2, b2 = self._stem_weights()
@@ -99,6 +102,10 @@ class WhisperDecoder(nn.Module):
 
     def forward(self, x: Tensor, memory: Tensor) -> Tensor:
         """tokens (B, L) int64, memory (B, S, d) -> logits (B, L, V) (tied embeddings), teacher-forced."""
+        if _cpu.on_cpu(x, self.token_embs.weight):
+            E = self.token_embs.weight
+            h = self.norm(self.layers(_cpu.embed_tokens(x, E, self.pos_embs), memory.to(E.dtype)))
+            return h @ E.T
         if self.token_embs.weight.dtype == torch.float32:  # fp32 parameters: fp32 throughout
             E = self.token_embs.weight
             h = self.norm(self.layers(ops.embed_tokens(x, E, self.pos_embs), memory.float()))
@@ -202,4 +209,6 @@ class WhisperPreprocessor(MelSpectrogram):
     def forward(self, x: Tensor) -> Tensor:
         """(..., T) waveform -> (..., n_mels, T // 160) log-mel: last frame dropped, log10, floored at the
         PER-SAMPLE max - 8, (x + 4) / 4 - all inside the two logmel kernels."""
+        if _cpu.on_cpu(x, self.window, self.filters):
+            return _cpu.whisper_log_mel(x, self.window, self.filters)
         return ops.stft_mel(x, self._tables(), 400, 160, x.shape[-1] // 160, 2, self._csr(), self.filters.shape[0])

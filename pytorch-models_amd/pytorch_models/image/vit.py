@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from .. import _cpu
 from .._hip import ops
 from ..transformer import MHA, MLP, Encoder, LayerNorm, _f32, _fused_mlp, _wb, derived
 
@@ -77,6 +78,8 @@ class ViT(nn.Module):
 
     def tokens(self, imgs: Tensor) -> Tensor:
         """(N, 3, H, W) f32 -> (N, L [+1], d) bf16: patch projection + pe (+ cls) in one kernel."""
+        if _cpu.on_cpu(imgs, self.patch_embed.weight):
+            return _cpu.vit_tokens(self, imgs)
         if self.patch_embed.weight.dtype == torch.float32:
             return self._tokens_f32(imgs)
         pw = self.patch_embed.weight
@@ -123,6 +126,8 @@ class ViT(nn.Module):
         if isinstance(self.pooler, ClassTokenPooling):
             # LayerNorm is row-wise, so normalising only the pooled row equals norm-then-pool (vit.py:83-84)
             return self.norm(out[:, 0], io)
+        if out.device.type == "cpu":
+            return self.pooler(self.norm(out))
         return self.pooler(self.norm(out)).to(io)
 
     @torch.no_grad()

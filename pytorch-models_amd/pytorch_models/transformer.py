@@ -27,6 +27,7 @@ import os
 import torch
 from torch import Tensor, nn
 
+from . import _cpu
 from ._hip import ops
 
 _ACTS = {
@@ -89,8 +90,8 @@ def _require_bf16(x: Tensor, w: Tensor, who: str) -> None:
     """Device and dtype gate of every block: HIP tensors, bf16 or fp32 (each computed in its own dtype, see above)."""
     if not x.is_cuda or not w.is_cuda:
         raise RuntimeError(
-            f"{who}: the MI355X build of pytorch_models runs on HIP devices only (input on {x.device}, weights on "
-            f"{w.device}); there is no CPU path.")
+            f"{who}: input on {x.device}, weights on {w.device}: the HIP kernels take operands on ONE HIP device (a module and "
+            "its input both on the CPU take the plain-torch CPU forms instead).")
     if w.dtype not in _FLOATS or x.dtype not in _FLOATS:
         raise NotImplementedError(f"{who}: bf16 or fp32 only (weights {w.dtype}, input {x.dtype})")
 
@@ -126,8 +127,9 @@ class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm whose forward is pm_layernorm (parameter names unchanged)."""
 
     def forward(self, x: Tensor, out_dtype: torch.dtype | None = None) -> Tensor:
-        if not x.is_cuda:
-            raise RuntimeError("LayerNorm: HIP devices only (no CPU path)")
+        if _cpu.on_cpu(x, self.weight):  # CPU tensors, CPU parameters: plain torch (pytorch_models/_cpu.py)
+            y = torch.nn.functional.layer_norm(x.to(self.weight.dtype), self.normalized_shape, self.weight, self.bias, self.eps)
+            return y if out_dtype is None else y.to(out_dtype)
         g = _f32(self, "g", self.weight)
         b = _f32(self, "b", self.bias)
         y = ops.layernorm(x.reshape(-1, x.shape[-1]), g, b, self.eps, out_dtype)
@@ -138,6 +140,8 @@ class Linear(nn.Linear):
     """nn.Linear whose forward is pm_linear_bf16 (parameter names unchanged)."""
 
     def forward(self, x: Tensor) -> Tensor:
+        if _cpu.on_cpu(x, self.weight):
+            return _cpu.linear(x, self.weight, self.bias)
         _require_bf16(x, self.weight, "Linear")
         if _is32(self.weight):  # fp32 parameters: fp32 arithmetic
             y = ops.linear_f32(x.float().reshape(-1, x.shape[-1]), self.weight, self.bias)
@@ -214,6 +218,8 @@ class MHA(nn.Module):
 
     def attend(self, q, k=None, v=None, attn_bias=None, causal=False, residual: Tensor | None = None) -> Tensor:
         """forward() plus an optional residual that is added inside the out_proj kernel's epilogue."""
+        if _cpu.on_cpu(q, self.q_proj.weight):
+            return _cpu.mha(self, q, k, v, attn_bias, causal, residual)
         _require_bf16(q, self.q_proj.weight, "MHA")
         if self.head_dim % 2 or self.head_dim > 128 or (self.head_dim % 4 and self.head_dim > 64):
             raise NotImplementedError(f"MHA: head_dim {self.head_dim} is not covered by the gfx950 attention kernels (% 4 up to 128, % 2 up to 64)")
@@ -333,6 +339,8 @@ class MLP(nn.Module):
         return self.run(x)
 
     def run(self, x: Tensor, residual: Tensor | None = None) -> Tensor:
+        if _cpu.on_cpu(x, self.linear1.weight):
+            return _cpu.mlp(self, x, residual)
         _require_bf16(x, self.linear1.weight, "MLP")
         if self.training and self.dropout.p > 0.0:
             raise NotImplementedError("MLP: inference only (dropout is not implemented)")

@@ -107,13 +107,24 @@ def test_state_dict_roundtrip_and_derived_cache_invalidation():
     assert "_pm_derived" not in m.state_dict()
 
 
-def test_no_cpu_path():
-    """The product never computes on the CPU: a CPU tensor raises instead of silently falling back."""
-    m = EncoderLayer(64).to(torch.bfloat16)
+def test_cpu_tensors_take_the_cpu_forms_and_never_the_hip_library(monkeypatch):
+    """A module and its input both on the CPU compute in plain torch (pytorch_models/_cpu.py: BASELINE configs[0]); the HIP
+    library is not touched, and - the other half of "no silent fallback" - the families whose kernels are HIP-only still
+    refuse a CPU model.  (HIP tensors with a missing library raise in pytorch_models._hip.lib: tests/test_abi.py.)"""
+    from pytorch_models import _hip
+
+    def boom():
+        raise AssertionError("a CPU forward called into libpm_mi355x.so")
+
+    monkeypatch.setattr(_hip, "lib", boom)
+    monkeypatch.setattr(_hip.ops, "lib", boom)
+    y = EncoderLayer(64)(torch.zeros(1, 4, 64))
+    assert y.shape == (1, 4, 64) and y.device.type == "cpu"
+    assert ViT(1, 64, 1, 16, img_size=32)(torch.zeros(1, 3, 32, 32)).shape == (1, 64)
+    from pytorch_models.transformer import require_bf16_params
+
     with pytest.raises(RuntimeError, match="HIP devices only"):
-        m(torch.zeros(1, 4, 64, dtype=torch.bfloat16))
-    with pytest.raises(RuntimeError, match="HIP devices only"):
-        ViT(1, 64, 1, 16, img_size=32).to(torch.bfloat16)(torch.zeros(1, 3, 32, 32))
+        require_bf16_params(EncoderLayer(64), "T5")
 
 
 def test_mel_filters_match_reference_golden(golden):
