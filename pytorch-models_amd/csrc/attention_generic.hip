@@ -6,7 +6,14 @@
 //
 // Correctness-first and off the benchmark path (every BASELINE config has head_dim 64): fp32 VALU arithmetic, a
 // workgroup handles 8 queries of one (batch, head), scores for all keys parked in LDS (Lk <= 2048), exact softmax.
+#include <cstdlib>
+
 #include "common.h"
+
+// attention_f32.hip
+int pm_attention_f32_hd64_launch(const float* q, int64_t qsb, int64_t qst, const float* k, int64_t ksb, int64_t kst, const float* v,
+                                 int64_t vsb, int64_t vst, float* o, int64_t osb, int64_t ost, int64_t B, int64_t H, int64_t Lq,
+                                 int64_t Lk, hipStream_t st);
 
 namespace {
 
@@ -245,6 +252,15 @@ extern "C" int pm_attention_generic_f32(const float* q, int64_t q_stride_b, int6
   if ((q_stride_t | k_stride_t | v_stride_t | q_stride_b | k_stride_b | v_stride_b | o_stride_t | o_stride_b) % unit32) return PM_EALIGN;
   if (((uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & (unit32 * 4 - 1)) return PM_EALIGN;
   if (bias && bias_stride_q < Lk) return PM_EINVAL;
+  // head_dim 64 without mask / bias (encoder layers, ViT): the f32-input matrix pipe (attention_f32.hip), same fp32 arithmetic
+  static const bool f32_mfma = [] { const char* e = getenv("PM_ATTN_F32_MFMA"); return !e || atoi(e) != 0; }();
+  if (f32_mfma && head_dim == 64 && !causal && !bias && !(((uintptr_t)q) & 15) && q_stride_t % 4 == 0 && q_stride_b % 4 == 0) {
+    const int rc = pm_attention_f32_hd64_launch(q, q_stride_b, q_stride_t, k, k_stride_b, k_stride_t, v, v_stride_b, v_stride_t, o,
+                                                o_stride_b, o_stride_t, B, H, Lq, Lk, (hipStream_t)stream);
+    if (rc != PM_OK) return rc;
+    PM_CHECK_LAUNCH();
+    return PM_OK;
+  }
   const int nqb = (int)((Lq + GQ - 1) / GQ);
   const int64_t nblk = B * H * nqb;
   if (nblk > 0x7fffffff) return PM_EINVAL;

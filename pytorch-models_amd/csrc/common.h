@@ -44,6 +44,7 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __u
 // async global -> LDS copy of 16 B per lane; the LDS destination is wave-uniform base + lane*16
 #ifndef PM_GLDS_AUX
 #define PM_GLDS_AUX 0  // cache-policy bits of the LDS-DMA loads: 1 = sc0, 2 = nt, 16 = sc1 (experiments; 0 in the product)
+#endif
 // Output rows of the large-M GEMMs: 1 = non-temporal stores (the L2 does not keep what the next kernel re-reads from HBM / the
 // Infinity Cache anyway, so the operand panels keep their lines)
 #ifndef PM_Y_NT
@@ -57,7 +58,6 @@ __device__ __forceinline__ void store_y(V* p, V v) {
   *p = v;
 #endif
 }
-#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base) {
   __builtin_amdgcn_global_load_lds((const PM_GLOBAL void*)gsrc, (PM_LDS void*)lds_dst_wave_base, 16, 0, PM_GLDS_AUX);
 }

@@ -577,6 +577,9 @@ def whisper_stem1(x: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
     return out
 
 
+EMBED_CHECK_IDS = True  # embed_tokens validates ids against the vocabulary (one read-back per eager call)
+
+
 def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor | None, pos0: int = 0, out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
     """tokens int64 (B, L) -> (B, L, d): emb[tokens] + pos[pos0 : pos0 + L] (pos None: no positional term)."""
     _cuda(tokens, emb, pos)
@@ -586,12 +589,14 @@ def embed_tokens(tokens: Tensor, emb: Tensor, pos: Tensor | None, pos0: int = 0,
     V, d = emb.shape
     _need(emb.dtype in (torch.bfloat16, torch.float32) and emb.is_contiguous(), "embed_tokens: emb bf16 or f32 (V, d)")
     # nn.Embedding raises on an id outside [0, V) (whisper.py:48); the kernel clamps so that a bad id cannot fault, so
-    # the range is checked here (one min / max read-back; skipped inside a graph capture, where the caller has
-    # validated the example inputs eagerly during the warm-up pass)
-    if tokens.numel() and not torch.cuda.is_current_stream_capturing():
-        lo, hi = int(tokens.min()), int(tokens.max())
-        if lo < 0 or hi >= V:
-            raise IndexError(f"embed_tokens: token id {lo if lo < 0 else hi} outside the vocabulary [0, {V})")
+    # the range is checked here (skipped inside a graph capture, where the caller has validated the example inputs eagerly
+    # during the warm-up pass)
+    # ONE read-back (min and max were two host synchronisations per teacher-forced forward); EMBED_CHECK_IDS = False
+    # skips it for loops that have validated their ids (a generator feeding back its own arg-max ids)
+    if EMBED_CHECK_IDS and tokens.numel() and not torch.cuda.is_current_stream_capturing():
+        if bool(((tokens < 0) | (tokens >= V)).any()):
+            bad = tokens[(tokens < 0) | (tokens >= V)][0].item()
+            raise IndexError(f"embed_tokens: token id {bad} outside the vocabulary [0, {V})")
     if pos is not None:
         _need(pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[1] == d and pos.shape[0] >= pos0 + L,
               f"embed_tokens: need {pos0 + L} position rows, have {pos.shape[0]}")

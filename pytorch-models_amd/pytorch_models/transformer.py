@@ -526,6 +526,15 @@ class Encoder(nn.Sequential):
         device = halves[0].device if producers is None else device
         cur = torch.cuda.current_stream(device)
         streams = [cur] + [_side_stream(device, k) for k in range(1, n_parts)]
+        # The result is allocated on the caller's stream BEFORE the fork: a block the caller's stream freed earlier can
+        # then only be handed out while everything the side streams do is still ordered behind it by the wait below; every
+        # tensor a side stream allocates also dies on it, so the caching allocator needs no cross-stream bookkeeping.
+        out = None
+        if producers is None:
+            out = torch.empty_like(x)
+        elif getattr(self, "_pm_out_shape", None) is not None:
+            shape, dtype = self._pm_out_shape
+            out = torch.empty(shape, dtype=dtype, device=device)
         for st in streams[1:]:
             st.wait_stream(cur)
         if producers is None:
@@ -539,9 +548,13 @@ class Encoder(nn.Sequential):
         first = [0]
         for t, _ in state:
             first.append(first[-1] + t.shape[0])
-        # the result is allocated on the caller's stream: every tensor a side stream allocates also dies on it, so the caching
-        # allocator needs no cross-stream bookkeeping (record_stream)
-        out = torch.empty((first[-1],) + tuple(state[0][0].shape[1:]), dtype=state[0][0].dtype, device=device)
+        want = ((first[-1],) + tuple(state[0][0].shape[1:]), state[0][0].dtype)
+        if out is None or (tuple(out.shape), out.dtype) != want:  # (producers: the shape is known once the first part exists)
+            out = torch.empty(want[0], dtype=want[1], device=device)
+            for st in streams[1:]:  # allocated behind the fork this once: order the side streams behind the allocation
+                st.wait_stream(cur)
+        if producers is not None:
+            self._pm_out_shape = want  # the next call with this geometry allocates in front of the fork
         if any(o != oks[0] for o in oks[1:]):  # (producers only; rare) different paths per part: one piece on the caller's stream
             for k in range(n_parts):
                 with torch.cuda.stream(streams[k]):

@@ -53,7 +53,9 @@ for (M, N, K, act, resid, rows, lnc) in ([] if "--time-only" in sys.argv else ca
     bad += not ok
     print(f"kernel={which} M={M} N={N} K={K} act={act} resid={resid} rows={rows} lnc={lnc}: max|err| {err:.3e} (tol {tol:.3e}) rerun-identical {bool(torch.equal(out, out2))}{msg} {'OK' if ok else 'FAIL'}", flush=True)
 if "--time" in sys.argv or "--time-only" in sys.argv:
-    for (M, N, K, act, resid, rows, lnc) in cases[:4] + [(25216, 768, 768, "none", True, True, False), (25216, 768, 3072, "none", True, True, False), (8192, 8192, 8192, "none", False, False, False)]:
+    for (M, N, K, act, resid, rows, lnc) in cases[:4] + [(25216, 768, 768, "none", True, True, False), (25216, 768, 3072, "none", True, True, False),
+                                                      (25216, 3072, 768, "gelu", False, False, True), (25216, 2304, 768, "none", False, False, True),
+                                                      (8192, 8192, 8192, "none", False, False, False)]:
         x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
         w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
         b = torch.randn(N, device="cuda")

@@ -58,6 +58,7 @@ log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
 groups = {}
 for name, evs in log.items():
     for a, b, work in evs:
+        work = work[0] if isinstance(work, tuple) else work  # ops.linear logs (flop, bytes), the other wrappers a float
         g = groups.setdefault((name, work), [0, 0.0])
         g[0] += 1
         g[1] += a.elapsed_time(b)
