@@ -200,3 +200,26 @@ def test_whisper_large_v2_geometry_config4():
     toks = w.decoder.generate(memory, prompt.cuda(), 8)
     want, margins = RW.greedy_cached(sd, "decoder.", prompt, memory.float().cpu(), 8, rp=kv_round)
     assert _compare(toks, want, margins, 4) == 0
+
+
+def test_whisper_large_v2_config4_per_gpu_batch_32_properties():
+    """BASELINE configs[3] at its per-GPU size (batch 256 over 8 GPUs = 32 clips per GPU; large-v2: 32 layers, d = 1280, 20
+    heads, 224 new tokens).  The oracle cannot follow this in minutes, so: (a) ids in range; (b) batch invariance - rows 0-1
+    equal the batch-2 run of the same clips (the unfused self-attention and row-split projections of the 640-pair geometry
+    against the fused ones of the 40-pair geometry: same fp32 arithmetic per row), which the geometry test above ties to
+    the oracle for its first tokens; (c) a second run is bit-identical (order-fixed reductions, K-split tickets)."""
+    from pytorch_models.audio2text import Whisper
+
+    w = Whisper.from_openai("large-v2").eval()
+    fill_module(w, 57)
+    bf16_round_(w)
+    w = w.to(torch.bfloat16).cuda()
+    memory2 = (synth_input("w_mem_large", (2, 1500, 1280), 59, scale=1.0)).to(torch.bfloat16).cuda()
+    prompt2 = synth_tokens("w_prompt_large2", (2, 4), 51865, 59).cuda()
+    memory = memory2.repeat(16, 1, 1).contiguous()
+    prompt = prompt2.repeat(16, 1).contiguous()
+    toks = w.decoder.generate(memory, prompt, 224)
+    assert toks.shape == (32, 228) and int(toks.min()) >= 0 and int(toks.max()) < 51865
+    small = w.decoder.generate(memory2, prompt2, 224)
+    assert torch.equal(toks[:2], small) and torch.equal(toks[30:32], small)
+    assert torch.equal(w.decoder.generate(memory, prompt, 224), toks)

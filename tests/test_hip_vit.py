@@ -77,6 +77,25 @@ def test_vit_l16_siglip384_config5_geometry(golden):
     check(got, golden("vit")["l16_siglip384_b2"])
 
 
+def test_vit_l16_siglip384_config5_per_gpu_batch_256_properties(golden):
+    """BASELINE configs[4] at its per-GPU size (batch 2048 over 8 GPUs = 256 images of 384 x 384 per GPU; 147456 token rows of
+    1024: the 320 x 256 / 256 x 256 tile GEMMs, two streams, attention at L = 576).  The oracle cannot follow 256 such images, so:
+    (a) the first 2 rows equal the batch-2 run, which the test above ties to the reference's golden; (b) permuting the batch
+    permutes the output rows bit-exactly; (c) finite outputs; (d) a second run is bit-identical."""
+    m, _, _ = build(lambda V: V.from_google("L/16_siglip", img_size=384), 34)
+    x2 = synth_input("vit_ls", (2, 3, 384, 384), 34).cuda()
+    big = synth_input("vit_ls256", (256, 3, 384, 384), 78).cuda()
+    big[:2] = x2
+    out = m(big)
+    assert out.shape == (256, 1024) and torch.isfinite(out.float()).all()
+    small = m(x2).float()
+    assert ((out[:2].float() - small).norm() / small.norm()).item() < 1e-2  # folded / unfolded LayerNorms: rounding points differ
+    check(out[:2], golden("vit")["l16_siglip384_b2"])
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(2)).cuda()
+    torch.testing.assert_close(m(big[perm]), out[perm], rtol=0, atol=0)
+    torch.testing.assert_close(m(big), out, rtol=0, atol=0)
+
+
 def test_vit_gap_pooler_and_resize_pe(golden):
     from pytorch_models.image import ViT
 
