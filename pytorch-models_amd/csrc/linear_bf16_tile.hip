@@ -168,7 +168,15 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
   for (int pc = 0; pc < P; ++pc) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // two stages: only step pc itself was in flight
     __builtin_amdgcn_s_barrier();                     // every wave's part landed; every wave is past step pc-1: its buffer is free
-    PM_TSTAGE_NEXT();
+    // The two waves of a SIMD never request at the same time (PM_TILE_ISSUE_SPLIT 1; 0 = both right here): waves 0-3 request
+    // their pieces of the next stage here, waves 4-7 theirs behind the MFMAs of the first half step (below).  An LDS-DMA
+    // piece costs its wave ~60-100 cycles of issue during which the wave issues nothing else; with both partners in that
+    // phase right behind the barrier the SIMD's matrix pipe stood idle for ~500-900 of a step's ~4700 cycles.  Now one
+    // partner's MFMAs run under the other's requests: fc2 234 -> 208 us, 8192^3 802 -> 741 (1.48 PFLOP/s), QKV 165 -> 154.
+#ifndef PM_TILE_ISSUE_SPLIT
+#define PM_TILE_ISSUE_SPLIT 1
+#endif
+    if (!PM_TILE_ISSUE_SPLIT || (PM_TILE_ISSUE_SPLIT == 1 && wave < 4)) PM_TSTAGE_NEXT();
     if (kt == nk - 1) {
       // last K step of the tile: request what the epilogue needs first now, so that the latency hides under this step's MFMAs
       int tm_r, tn_r;
@@ -199,6 +207,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = tread(wcur, wn * 128 + j * 16 + fr, ss * 4 + fq);
       __builtin_amdgcn_sched_barrier(0);
+      if (PM_TILE_ISSUE_SPLIT == 2 && ss == (wave < 4 ? 0 : 1)) {  // measured equal or slower: requests between a half step's fragment reads and its MFMAs
+        PM_TSTAGE_NEXT();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (kt == 0 && ss == 0) {  // a tile's first step starts from the constant 0: nobody has to clear the accumulators
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -212,6 +224,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
           for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
       }
       if (MI > 4) __builtin_amdgcn_sched_barrier(0);  // 212 of 256 registers are accumulators + fragments: no hoisting of the next reads
+      if (PM_TILE_ISSUE_SPLIT == 1 && ss == 0 && wave >= 4) {
+        PM_TSTAGE_NEXT();  // waves 4-7: half a step behind their SIMD partners (see the top of the step)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     buf ^= 1;
     if (++kt < nk) continue;
