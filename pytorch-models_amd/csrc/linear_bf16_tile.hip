@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 #ifndef PM_TILE_ISSUE_SPLIT
 #define PM_TILE_ISSUE_SPLIT 1
 #endif
-    if (!PM_TILE_ISSUE_SPLIT || (PM_TILE_ISSUE_SPLIT == 1 && wave < 4)) PM_TSTAGE_NEXT();
+    if (!PM_TILE_ISSUE_SPLIT || wave < 4) PM_TSTAGE_NEXT();
     if (kt == nk - 1) {
       // last K step of the tile: request what the epilogue needs first now, so that the latency hides under this step's MFMAs
       int tm_r, tn_r;
@@ -207,10 +207,6 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] = tread(wcur, wn * 128 + j * 16 + fr, ss * 4 + fq);
       __builtin_amdgcn_sched_barrier(0);
-      if (PM_TILE_ISSUE_SPLIT == 2 && ss == (wave < 4 ? 0 : 1)) {  // measured equal or slower: requests between a half step's fragment reads and its MFMAs
-        PM_TSTAGE_NEXT();
-        __builtin_amdgcn_sched_barrier(0);
-      }
       if (kt == 0 && ss == 0) {  // a tile's first step starts from the constant 0: nobody has to clear the accumulators
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -224,7 +220,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
           for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
       }
       if (MI > 4) __builtin_amdgcn_sched_barrier(0);  // 212 of 256 registers are accumulators + fragments: no hoisting of the next reads
-      if (PM_TILE_ISSUE_SPLIT == 1 && ss == 0 && wave >= 4) {
+      // (other placements measured equal or slower: both partners between a half step's fragment reads and its MFMAs; waves
+      // 0-3 there and waves 4-7 here; four request points by wave pair)
+      if (PM_TILE_ISSUE_SPLIT && ss == 0 && wave >= 4) {
         PM_TSTAGE_NEXT();  // waves 4-7: half a step behind their SIMD partners (see the top of the step)
         __builtin_amdgcn_sched_barrier(0);
       }
