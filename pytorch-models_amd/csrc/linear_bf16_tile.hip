@@ -202,23 +202,75 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       bf16x8 a[8], b[MI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) b[i] = tread(xcur, wm * WR + i * 16 + fr, ss * 4 + fq);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = tread(wcur, wn * 128 + j * 16 + fr, ss * 4 + fq);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt == 0 && ss == 0) {  // a tile's first step starts from the constant 0: nobody has to clear the accumulators
+      // Fragment reads in the order of their first use and the weight subtiles' MFMAs in that order, both pinned, in ONE basic
+      // block per case (a tile's first half step starts from the constant 0: nobody clears accumulators): hipcc then waits
+      // lgkmcnt(7) for the first 5 (MI) MFMAs and one fragment more per subtile - left to itself it issued the weight fragments
+      // in reverse and waited lgkmcnt(0) for all MI + 8 in front of the first MFMA; and a branch between the reads and the MFMAs
+      // makes it wait for everything at the block's entry.
+#ifndef PM_TILE_ASM_READS
+#define PM_TILE_ASM_READS 1
+#endif
+      // (hipcc's own waits in front of these MFMAs are lgkmcnt(0) whatever the order - it waits for all MI + 8 fragments before
+      // the first MFMA -, so the fragment reads are inline asm it does not track, and each subtile's MFMAs sit behind a counted
+      // wait that takes the fragments as operands: nothing that uses them can be scheduled above it.)
+#if PM_TILE_ASM_READS
+#define PM_TREAD1(dst_, base_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(base_), "n"(off_))
+#define PM_TWAIT(n_, j_)                                                                                             \
+  if constexpr (MI == 5)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[j_]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[MI - 1]) : "n"(n_)); \
+  else                                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[j_]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(n_));
+#define PM_TREADS()                                                                                                  \
+  {                                                                                                                  \
+    const uint32_t sw_ = (uint32_t)(((ss * 4 + fq) ^ ((fr >> 1) & 7)) * 16 + fr * 128);                              \
+    const uint32_t xb_ = (uint32_t)(uintptr_t)(PM_LDS const char*)xcur + (uint32_t)(wm * WR * 128) + sw_;            \
+    const uint32_t wb_ = (uint32_t)(uintptr_t)(PM_LDS const char*)xcur + (uint32_t)(wn * 128 * 128) + sw_;           \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) PM_TREAD1(b[i], xb_, i * 2048);                                   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) PM_TREAD1(a[j], wb_, BM * 128 + j * 2048);                         \
+  }
+#else
+#define PM_TWAIT(n_, j_)
+#define PM_TREADS()                                                                                                  \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) b[i] = tread(xcur, wm * WR + i * 16 + fr, ss * 4 + fq);           \
+    a[0] = tread(wcur, wn * 128 + fr, ss * 4 + fq);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    _Pragma("unroll") for (int j = 1; j < 8; ++j) {                                                                  \
+      a[j] = tread(wcur, wn * 128 + j * 16 + fr, ss * 4 + fq);                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }                                                                                                                \
+  }
+#endif
+      // subtile j's MFMAs: its own fragment and everything older have landed (7 - j younger reads may still be in flight)
+#define PM_TWAIT_J(j_)                                                                                               \
+  {                                                                                                                  \
+    if ((j_) == 0) { PM_TWAIT(7, 0) } else if ((j_) == 1) { PM_TWAIT(6, 1) } else if ((j_) == 2) { PM_TWAIT(5, 2) }  \
+    else if ((j_) == 3) { PM_TWAIT(4, 3) } else if ((j_) == 4) { PM_TWAIT(3, 4) } else if ((j_) == 5) { PM_TWAIT(2, 5) } \
+    else if ((j_) == 6) { PM_TWAIT(1, 6) } else { PM_TWAIT(0, 7) }                                                   \
+  }
+      if (kt == 0 && ss == 0) {
+        PM_TREADS();
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
+          PM_TWAIT_J(j);
 #pragma unroll
           for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], zero, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
+        PM_TREADS();
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
+          PM_TWAIT_J(j);
 #pragma unroll
           for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], b[i], acc[j][i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+#undef PM_TREADS
+#undef PM_TWAIT_J
+#undef PM_TWAIT
       if (MI > 4) __builtin_amdgcn_sched_barrier(0);  // 212 of 256 registers are accumulators + fragments: no hoisting of the next reads
       // (other placements measured equal or slower: both partners between a half step's fragment reads and its MFMAs; waves
       // 0-3 there and waves 4-7 here; four request points by wave pair)
