@@ -314,6 +314,29 @@ int pm_dec_attention_fused_kv32(const float* x, int64_t d, const float* gamma, c
                                 const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, float* out, int64_t B, int64_t H,
                                 int self_attn, void* stream);
 
+/* pm_dec_attention_fused (kv_f32 = 0) / _kv32 (kv_f32 = 1) as a link of the step's chain of DEFERRED SUMS: two launches per
+ * layer and the K-split's ticket leave the chain (transformer.py:50-53 and the residual adds of transformer.py:96-100, same sums).
+ *   IN  - the block's input row is  x[b] + x_bias + sum_{p < n_parts} x_parts[p * part_stride + b * part_row_stride + :]  (added in
+ *         part order; every (b, h) workgroup forms it itself), and workgroup (b, 0) writes it to x_out (must not alias x) as the
+ *         residual stream for what follows.  n_parts = 0: plain x, x_out untouched.  Producers: pm_dec_linear_kparts (fc2 of the
+ *         previous layer: part_stride = its part_stride, part_row_stride = ld_parts) and this function's own OUT side
+ *         (part_stride = d, part_row_stride = H * d, x_bias = the output projection's bias).
+ *   OUT - w_out != NULL (bf16 (d, H*64) row-major): instead of att the block writes the output projection's per-head partial sums
+ *         head_parts[(b * H + h) * d + n] = sum_j att[b, h*64 + j] * w_out[n, h*64 + j]  (fp32 FMA chain); `out` is not written.
+ *         w_out == NULL: att to `out` as pm_dec_attention_fused.
+ * Other arguments as pm_dec_attention_fused. */
+int pm_dec_attention_chain(const float* x, int64_t d, const float* gamma, const float* beta, float eps, const void* w,
+                           const float* bias, void* kc, void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
+                           const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, int64_t B, int64_t H, int self_attn,
+                           int kv_f32, const float* x_parts, int64_t n_parts, int64_t part_stride, int64_t part_row_stride,
+                           const float* x_bias, float* x_out, const void* w_out, float* head_parts, float* out, void* stream);
+
+/* pm_dec_linear_ksplit's products WITHOUT the combining pass: part p (K steps [p, p + 1) * K / k_split) of x w^T goes to
+ * parts + p * part_stride, row stride ld_parts, as it stands - no bias, no residual, no ticket; the consumer
+ * (pm_dec_attention_chain) adds the parts in order.  part_stride >= M * ld_parts, both % 4 == 0, parts 16-byte aligned. */
+int pm_dec_linear_kparts(const float* x, int64_t ldx, const void* w, int64_t ldw, float* parts, int64_t ld_parts,
+                         int64_t part_stride, int64_t M, int64_t N, int64_t K, int64_t k_split, void* stream);
+
 /* Finish the argmax over the n_tiles tile winners of pm_dec_linear mode 2 (lowest index on ties, like torch.argmax),
  * teacher-force the prompt (next = prompt[b, t+1] while t + 1 < P), write tok_cur[b] and tokens_out[b, t+1]. */
 int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_tiles, const int32_t* pos_ptr,

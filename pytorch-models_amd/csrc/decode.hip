@@ -40,7 +40,7 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
-enum { DL_PLAIN = 0, DL_QKV = 1, DL_ARGMAX = 2 };
+enum { DL_PLAIN = 0, DL_QKV = 1, DL_ARGMAX = 2, DL_PARTS = 3 };
 
 // Workgroup barrier for data exchanged through LDS only.  __syncthreads() carries a fence that waits for EVERY outstanding
 // memory operation - also the global loads a kernel has deliberately left in flight (its weight stream) - so a reduction in the
@@ -256,6 +256,26 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
       for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + (((w * FT + f) * MT + t) * 64 + lane) * 4);
       vs[f][t] = v;
     }
+  if (mode == DL_PARTS) {
+    // K split whose parts are added by the consumer (dec_attn_fused_kernel CHAIN: the next block forms x + bias + parts itself):
+    // part kp goes to out + kp * ldr as it stands - no ticket, no second pass, nothing after the store
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const int n = n0 + f * 16 + kq * 4;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int row = rbase + t * 16 + fi;
+        float* o = out + (int64_t)kp * ldr + (int64_t)row * ldo + n;
+        if (row < M && n + 3 < N) *(f32x4*)o = vs[f][t];
+        else if (row < M) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) o[r] = vs[f][t][r];
+        }
+      }
+    }
+    return;
+  }
   if (kparts > 1) {
     // K split: publish this part's tile (sc1 stores), take a ticket, and only the last part to finish goes on: it adds
     // the parts in part order (deterministic) and runs the epilogue.  Hand-off as in MI355X_MICROARCH.md (first row of
@@ -694,9 +714,40 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 // projection for one (b, h) is a 64 x d (or 192 x d) GEMV whose weights sit in L2, shared by the 32 sequences.
 // The K/V stream is what bounds the cross block (HBM): 8 waves x 8 x 16 B per lane = 64 KiB in flight per CU.
 #ifndef PM_CROSS_NKU
-#define PM_CROSS_NKU 4
+#define PM_CROSS_NKU 8
 #endif
 constexpr int DF_THREADS = 512, DF_WAVES = 8;
+#ifndef PM_CROSS_DB
+#define PM_CROSS_DB 1
+#endif
+#ifndef PM_CROSS_ONEPASS
+#define PM_CROSS_ONEPASS 0  // measured: 25.3 us per cross block against 22.9 for the two-pass form (profiles/r03)
+#endif
+#ifndef PM_CROSS_NKU1
+#define PM_CROSS_NKU1 4  // keys per lane group and step of the one-pass form (K + V: 2 x NKU1 x 16 B per lane and register set)
+#endif
+// In-kernel phase stamps of the fused attention block (variant builds only: tools/build_variant.sh stamps -DPM_DF_STAMPS=1;
+// tools/chain_stamps.py reads them through pm_debug_df_stamps)
+#ifndef PM_DF_STAMPS
+#define PM_DF_STAMPS 0
+#endif
+#if PM_DF_STAMPS
+__device__ unsigned long long g_df_stamps[1024 * 16];
+#define PM_STAMP(i_)                                                                                  \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_df_stamps[blockIdx.x * 16 + (i_)] = wall_clock64();  \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+extern "C" int pm_debug_df_stamps(void* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_df_stamps), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : 1;
+}
+#else
+#define PM_STAMP(i_)
+#endif
+#ifndef PM_CHAIN_ABL
+#define PM_CHAIN_ABL 0  // ablation builds of the chain's OUT side (tools/chain_bench.py): 1 no W_o loads, 2 one row of eight, 3 no store
+#endif
 
 // Block-wide sum / max over 8 waves through ONE barrier: every call site owns its 8-float slot of the scratch array, so
 // no barrier is needed to protect the slot's previous use (the kernel runs each reduction once).
@@ -718,12 +769,27 @@ template <typename KT> struct KV8;
 template <> struct KV8<bf16> { typedef bf16x8 type; };
 template <> struct KV8<float> { typedef f32x8 type; };
 
-template <bool SELF, int NCH, typename KT>
+// CHAIN: the block takes part in the step's deferred sums, on both sides, so that two launches per layer and the K-split's
+// ticket disappear from the chain.
+//  * IN: the residual stream row arrives as  x[b] + x_bias + sum_p x_parts[p][b]  (p in order: a fixed order, so nothing depends
+//    on timing) - the producer was a K-split projection that left its parts (pm_dec_linear_kparts: fc2 of the previous layer)
+//    or the previous attention block's per-head projection partials (below).  Every (b, h) workgroup forms the sum itself
+//    (n_parts + 2 loads in flight together instead of one: no extra round trip); workgroup (b, 0) also writes the row to
+//    x_out, which must not alias x (the other heads of b may still be reading it).
+//  * OUT (Wo != null): instead of its 64 attention outputs the workgroup writes their product with its 64 columns of W_o
+//    (d x 64, requested before the softmax: long landed when used) as d partial sums to head_parts[b][h][:]; the consumer
+//    adds the heads in order, with W_o's bias and the residual.
+// Measured first as "the last of a sequence's heads to finish adds them" (agent-scope ticket): the store -> ticket -> load
+// round trips cost the block 5-6 us, as much as the launch they replaced.
+template <bool SELF, int NCH, typename KT, bool CHAIN>
 __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     const float* __restrict__ x, int d, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const bf16* __restrict__ Wp, const float* __restrict__ bp,  // SELF: packed [q|k|v] (3*inner, d); cross: q (inner, d)
     KT* Kc, KT* Vc, int64_t sb, int64_t sh, int64_t sk, const int* __restrict__ pos_ptr, int lk_const,
-    float* __restrict__ out, int H) {
+    float* __restrict__ out, int H,
+    // CHAIN only:
+    const float* __restrict__ xparts, int np, int64_t xpstride, int64_t xprow, const float* __restrict__ xbias,
+    float* __restrict__ xout, const bf16* __restrict__ Wo, float* __restrict__ hparts) {
   typedef typename KV8<KT>::type kv8;
   __shared__ float sc[DA_MAXK];
   __shared__ float xn[1280];
@@ -739,12 +805,35 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   // ---- everything small that the chain LayerNorm -> projection needs is requested FIRST, in the order of its use: loads return
   // in order, so whatever is issued ahead of the row (weights, the K stream) delays the LayerNorm, and a gamma / beta / bias
   // load issued where it is used exposes one L2 latency each (measured: the block spent ~2 us of its 10-25 us waiting on them)
+  PM_STAMP(0);
   const float* xr = x + (int64_t)b * d;
   float xe[3], ge[3], be[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int k = tid + i * DF_THREADS;
     xe[i] = k < d ? xr[k] : 0.f;
+  }
+  // CHAIN, IN side: the first eight parts and the bias are REQUESTED here, behind the row, and added only after the projection
+  // weights and the first K passes have been requested too (below): consumed here they held every later request back by one
+  // memory round trip (+0.6-1.0 us per block, measured)
+  constexpr int XI = CHAIN ? (NCH * 64 + DF_THREADS - 1) / DF_THREADS : 1;  // row elements per thread of this instantiation
+  float xb[XI], pv[8][XI];
+  if constexpr (CHAIN) {
+    const float* pr = xparts + (int64_t)b * xprow;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int k = tid + i * DF_THREADS;
+      xb[i] = (np > 0 && xbias && k < d) ? xbias[k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pp = j < np ? j : np - 1;
+        pv[j][i] = (np > 0 && k < d) ? pr[pp * xpstride + k] : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int k = tid + i * DF_THREADS;
     ge[i] = k < d ? gamma[k] : 0.f;
     be[i] = k < d ? beta[k] : 0.f;
   }
@@ -771,7 +860,8 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   }
   // ---- the K stream does not depend on q: request its first NKU passes now - AFTER the projection weights, so the
   // weights are not queued behind it - and let HBM stream while the LayerNorm and the projection run.
-  constexpr int NKU = SELF ? 4 : PM_CROSS_NKU;
+  constexpr bool ONEPASS = !SELF && PM_CROSS_ONEPASS;  // K and V together, online softmax per lane group: see "one pass" below
+  constexpr int NKU = SELF ? 4 : ONEPASS ? (sizeof(KT) == 4 ? 2 : PM_CROSS_NKU1) : PM_CROSS_NKU;
   const int c = lane & 7, ks = lane >> 3;
   const KT* kb = Kc + b * sb + h * sh + c * 8;
   const KT* vb = Vc + b * sb + h * sh + c * 8;
@@ -783,6 +873,54 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
     kv[u] = SELF ? *(const kv8*)(kb + key * sk) : __builtin_nontemporal_load((const kv8*)(kb + key * sk));
   }
+  kv8 vv[NKU];
+  if constexpr (ONEPASS) {
+#pragma unroll
+    for (int u = 0; u < NKU; ++u) {
+      int key = u * 64 + wave * 8 + ks;
+      key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
+      vv[u] = __builtin_nontemporal_load((const kv8*)(vb + key * sk));
+    }
+  }
+  if constexpr (CHAIN) {
+    if (np > 0) {
+      __builtin_amdgcn_sched_barrier(0);  // (keep the requests above where they are)
+      float sp[XI];
+#pragma unroll
+      for (int i = 0; i < XI; ++i) sp[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < np) {
+#pragma unroll
+          for (int i = 0; i < XI; ++i) sp[i] += pv[j][i];
+        }
+      const float* pr = xparts + (int64_t)b * xprow;
+      for (int p0 = 8; p0 < np; p0 += 8) {  // more than eight parts (20 heads at d_model 1280): further groups, in part order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int pp = p0 + j < np ? p0 + j : np - 1;
+#pragma unroll
+          for (int i = 0; i < XI; ++i) {
+            const int k = tid + i * DF_THREADS;
+            pv[j][i] = k < d ? pr[pp * xpstride + k] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (p0 + j < np) {
+#pragma unroll
+            for (int i = 0; i < XI; ++i) sp[i] += pv[j][i];
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int k = tid + i * DF_THREADS;
+        xe[i] = (sp[i] + xb[i]) + xe[i];
+        if (h == 0 && k < d) xout[(int64_t)b * d + k] = xe[i];
+      }
+    }
+  }
+  PM_STAMP(1);
   // ---- LayerNorm of row b (two-pass from registers)
   float s = 0.f;
 #pragma unroll
@@ -801,6 +939,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     if (k < d) xn[k] = (xe[i] - mean) * rstd * ge[i] + be[i];
   }
   __syncthreads();
+  PM_STAMP(2);
   // ---- q (k, v) = W xn + b : fp32 FMA over this lane's chunks, then across the 8 lanes of the row
 #pragma unroll
   for (int o = 0; o < (SELF ? 3 : 1); ++o) {
@@ -833,104 +972,284 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   }
   __syncthreads();
 
-  // ---- scores
-  const f32x4 q0 = *(const f32x4*)(qkv + c * 8), q1 = *(const f32x4*)(qkv + c * 8 + 4);
-  for (int k0 = 0; k0 < Lc; k0 += 64 * NKU) {
-    if (k0 > 0) {
+  PM_STAMP(3);
+  float oval = 0.f;  // threads 0..63: the block's output element
+  // CHAIN with W_o: the head's 64 columns of W_o, 8 lanes per row (16 bytes each: whole 128-byte lines per request; one row per
+  // lane touched 64 lines per request and cost the block ~2 us), rows  pass * 512 + wave * 64 + i * 8 + (lane >> 3);  queued behind the first K / V groups
+  constexpr int NO = CHAIN ? (NCH * 64 + DF_THREADS - 1) / DF_THREADS : 1;
+  constexpr bool WO_EARLY = CHAIN && NO == 1;  // wider models: requested at the tail (NO x 32 registers would not fit here)
+  bf16x8 wo[NO][8];
+  if constexpr (WO_EARLY) {
+    if (Wo && PM_CHAIN_ABL != 1) {
 #pragma unroll
-      for (int u = 0; u < NKU; ++u) {
-        int key = k0 + u * 64 + wave * 8 + ks;
-        key = key < Lc ? key : Lc - 1;
-        kv[u] = SELF ? *(const kv8*)(kb + key * sk) : __builtin_nontemporal_load((const kv8*)(kb + key * sk));
+      for (int i = 0; i < 8; ++i) {
+        const int n = wave * 64 + i * 8 + (lane >> 3);
+        wo[0][i] = *(const bf16x8*)(Wo + (int64_t)(n < d ? n : d - 1) * inner + h * 64 + (lane & 7) * 8);
       }
     }
+  }
+  if constexpr (ONEPASS) {
+    // ---- one pass (the cross block): K and V of a key group are requested together and used together, every lane group (8 lanes =
+    // one key at a time, 64 lane groups per workgroup) keeps its own running maximum, sum and 8-wide accumulator, rescaled once
+    // per group of NKU keys; the 64 states are merged at the end (wave: shuffles, workgroup: LDS), in a fixed order.  Against the
+    // two-pass form (scores -> workgroup softmax -> P.V) the stream never stops: no score array, no barriers between the first
+    // key and the last, and the 2.4 us of softmax reductions between the passes (stamps: 5.1 K + 2.4 + 3.5 V of 16.6 us) are gone.
+    PM_STAMP(3);
+    const f32x4 q0 = *(const f32x4*)(qkv + c * 8), q1 = *(const f32x4*)(qkv + c * 8 + 4);
+    constexpr int KG = 64 * NKU;
+    float acc[8], m_run = -INFINITY, l_run = 0.f;
 #pragma unroll
-    for (int u = 0; u < NKU; ++u) {
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#define PM_KV_LOAD(dst_, base_, k0_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
+      int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                         \
+      key_ = key_ < Lc ? key_ : Lc - 1;                                                                                  \
+      dst_[u] = __builtin_nontemporal_load((const kv8*)(base_ + key_ * sk));                                             \
+    }
+#define PM_ONE_STEP(k_, v_, k0_)                                                                                       \
+    {                                                                                                                    \
+      float sv_[NKU], mg_ = -INFINITY;                                                                                   \
+      _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                  \
+        float t_ = 0.f;                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) t_ = fmaf(q0[i], (float)k_[u][i], t_);                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) t_ = fmaf(q1[i], (float)k_[u][4 + i], t_);                         \
+        t_ += __shfl_xor(t_, 1, 64);                                                                                     \
+        t_ += __shfl_xor(t_, 2, 64);                                                                                     \
+        t_ += __shfl_xor(t_, 4, 64);                                                                                     \
+        sv_[u] = (k0_) + u * 64 + wave * 8 + ks < Lc ? t_ * 0.125f : -INFINITY;                                          \
+        mg_ = fmaxf(mg_, sv_[u]);                                                                                        \
+      }                                                                                                                  \
+      const float mn_ = fmaxf(m_run, mg_);                                                                               \
+      if (mn_ > -INFINITY) { /* (a lane group whose keys all lie beyond Lc so far has nothing to add) */               \
+        const float f_ = expf(m_run - mn_);                                                                              \
+        l_run *= f_;                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] *= f_;                                                      \
+        _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                \
+          const float p_ = expf(sv_[u] - mn_);                                                                           \
+          l_run += p_;                                                                                                   \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] = fmaf(p_, (float)v_[u][i], acc[i]);                      \
+        }                                                                                                                \
+        m_run = mn_;                                                                                                     \
+      }                                                                                                                  \
+    }
+    {
+      kv8 kw[NKU], vw[NKU];
+      for (int k0 = 0; k0 < Lc;) {
+        if (k0 + KG < Lc) { PM_KV_LOAD(kw, kb, k0 + KG); PM_KV_LOAD(vw, vb, k0 + KG); }
+        PM_ONE_STEP(kv, vv, k0);
+        k0 += KG;
+        if (k0 >= Lc) break;
+        if (k0 + KG < Lc) { PM_KV_LOAD(kv, kb, k0 + KG); PM_KV_LOAD(vv, vb, k0 + KG); }
+        PM_ONE_STEP(kw, vw, k0);
+        k0 += KG;
+      }
+    }
+#undef PM_ONE_STEP
+#undef PM_KV_LOAD
+    PM_STAMP(6);
+    {  // merge: the 8 lane groups of the wave (lanes xor 8, 16, 32), then the 8 waves through LDS
+      float mw = m_run;
+      mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
+      mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+      mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+      const float f = m_run > -INFINITY ? expf(m_run - mw) : 0.f;
+      float lw = l_run * f;
+      lw += __shfl_xor(lw, 8, 64);
+      lw += __shfl_xor(lw, 16, 64);
+      lw += __shfl_xor(lw, 32, 64);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float a = acc[i] * f;
+        a += __shfl_xor(a, 8, 64);
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        acc[i] = a;
+      }
+      if (ks == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[wave * 64 + c * 8 + i] = acc[i];
+      }
+      if (lane == 0) { scratch[2 * DF_WAVES + wave] = mw; scratch[3 * DF_WAVES + wave] = lw; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float mall = scratch[2 * DF_WAVES];
+#pragma unroll
+      for (int w = 1; w < DF_WAVES; ++w) mall = fmaxf(mall, scratch[2 * DF_WAVES + w]);
+      float o = 0.f, lsum = 0.f;
+#pragma unroll
+      for (int w = 0; w < DF_WAVES; ++w) {
+        const float mwv = scratch[2 * DF_WAVES + w];
+        const float fw = mwv > -INFINITY ? expf(mwv - mall) : 0.f;
+        o = fmaf(part[w * 64 + tid], fw, o);
+        lsum = fmaf(scratch[3 * DF_WAVES + w], fw, lsum);
+      }
+      oval = o / lsum;
+    }
+  } else {
+    // ---- scores.  The cross block's 1500 keys are six groups of NKU x 64: the NEXT group is requested before this one is used
+    // (two register sets, the loop unrolled by two), so that 32-64 KB per CU stay in flight across the group boundary - with the
+    // request and its use in the same iteration every group exposed one full memory latency (PM_CROSS_DB=0 builds that form)
+    const f32x4 q0 = *(const f32x4*)(qkv + c * 8), q1 = *(const f32x4*)(qkv + c * 8 + 4);
+    constexpr int KG = 64 * NKU;
+#define PM_KV_LOAD(dst_, base_, k0_)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
+      int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                         \
+      key_ = key_ < Lc ? key_ : Lc - 1;                                                                                  \
+      dst_[u] = SELF ? *(const kv8*)(base_ + key_ * sk) : __builtin_nontemporal_load((const kv8*)(base_ + key_ * sk));    \
+    }
+#define PM_K_SCORES(src_, k0_)                                                                                         \
+    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
+      float sv = 0.f;                                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], (float)src_[u][i], sv);                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], (float)src_[u][4 + i], sv);                         \
+      sv += __shfl_xor(sv, 1, 64);                                                                                       \
+      sv += __shfl_xor(sv, 2, 64);                                                                                       \
+      sv += __shfl_xor(sv, 4, 64);                                                                                       \
+      const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
+      if (c == 0 && key_ < Lc) sc[key_] = sv * 0.125f;                                                                   \
+    }
+    if constexpr (!SELF && PM_CROSS_DB) {
+      kv8 kw[NKU];
+      for (int k0 = 0; k0 < Lc;) {
+        if (k0 + KG < Lc) PM_KV_LOAD(kw, kb, k0 + KG);
+        PM_K_SCORES(kv, k0);
+        k0 += KG;
+        if (k0 >= Lc) break;
+        if (k0 + KG < Lc) PM_KV_LOAD(kv, kb, k0 + KG);
+        PM_K_SCORES(kw, k0);
+        k0 += KG;
+      }
+    } else {
+      for (int k0 = 0; k0 < Lc; k0 += KG) {
+        if (k0 > 0) PM_KV_LOAD(kv, kb, k0);
+        PM_K_SCORES(kv, k0);
+      }
+    }
+    if (SELF && tid < 8) {  // the new key (position t), same summation shape as above
       float sv = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], (float)kv[u][i], sv);
+      for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], qkv[64 + c * 8 + i], sv);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], (float)kv[u][4 + i], sv);
+      for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], qkv[64 + c * 8 + 4 + i], sv);
       sv += __shfl_xor(sv, 1, 64);
       sv += __shfl_xor(sv, 2, 64);
       sv += __shfl_xor(sv, 4, 64);
-      const int key = k0 + u * 64 + wave * 8 + ks;
-      if (c == 0 && key < Lc) sc[key] = sv * 0.125f;
+      if (c == 0) sc[Lk - 1] = sv * 0.125f;
     }
-  }
-  if (SELF && tid < 8) {  // the new key (position t), same summation shape as above
-    float sv = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], qkv[64 + c * 8 + i], sv);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], qkv[64 + c * 8 + 4 + i], sv);
-    sv += __shfl_xor(sv, 1, 64);
-    sv += __shfl_xor(sv, 2, 64);
-    sv += __shfl_xor(sv, 4, 64);
-    if (c == 0) sc[Lk - 1] = sv * 0.125f;
-  }
-  // V does not depend on the scores: request the first NKU passes now, so they fly during the softmax reductions
-  kv8 vv[NKU];
-#pragma unroll
-  for (int u = 0; u < NKU; ++u) {
-    int key = u * 64 + wave * 8 + ks;
-    key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-    vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
-  }
-  __syncthreads();
-  float mx = -INFINITY;
-  for (int k = tid; k < Lk; k += DF_THREADS) mx = fmaxf(mx, sc[k]);
-  mx = block_reduce8(mx, scratch + 2 * DF_WAVES, true);
-  float sum = 0.f;
-  for (int k = tid; k < Lk; k += DF_THREADS) {
-    const float p = expf(sc[k] - mx);
-    sc[k] = p;
-    sum += p;
-  }
-  sum = block_reduce8(sum, scratch + 3 * DF_WAVES, false);  // its barrier also publishes the p values
-
-  // ---- P.V
-  float acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < Lc; k0 += 64 * NKU) {
-    if (k0 > 0) {
-#pragma unroll
-      for (int u = 0; u < NKU; ++u) {
-        int key = k0 + u * 64 + wave * 8 + ks;
-        key = key < Lc ? key : Lc - 1;
-        vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
-      }
-    }
+    PM_STAMP(4);
+    // V does not depend on the scores: request the first NKU passes now, so they fly during the softmax reductions
 #pragma unroll
     for (int u = 0; u < NKU; ++u) {
-      const int key = k0 + u * 64 + wave * 8 + ks;
-      const float p = key < Lc ? sc[key] : 0.f;
+      int key = u * 64 + wave * 8 + ks;
+      key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
+      vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = tid; k < Lk; k += DF_THREADS) mx = fmaxf(mx, sc[k]);
+    mx = block_reduce8(mx, scratch + 2 * DF_WAVES, true);
+    float sum = 0.f;
+    for (int k = tid; k < Lk; k += DF_THREADS) {
+      const float p = expf(sc[k] - mx);
+      sc[k] = p;
+      sum += p;
+    }
+    sum = block_reduce8(sum, scratch + 3 * DF_WAVES, false);  // its barrier also publishes the p values
+
+    PM_STAMP(5);
+    // ---- P.V
+    float acc[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, (float)vv[u][i], acc[i]);
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#define PM_PV(src_, k0_)                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
+      const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
+      const float p_ = key_ < Lc ? sc[key_] : 0.f;                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] = fmaf(p_, (float)src_[u][i], acc[i]);                        \
+    }
+    if constexpr (!SELF && PM_CROSS_DB) {
+      kv8 vw[NKU];
+      for (int k0 = 0; k0 < Lc;) {
+        if (k0 + KG < Lc) PM_KV_LOAD(vw, vb, k0 + KG);
+        PM_PV(vv, k0);
+        k0 += KG;
+        if (k0 >= Lc) break;
+        if (k0 + KG < Lc) PM_KV_LOAD(vv, vb, k0 + KG);
+        PM_PV(vw, k0);
+        k0 += KG;
+      }
+    } else {
+      for (int k0 = 0; k0 < Lc; k0 += KG) {
+        if (k0 > 0) PM_KV_LOAD(vv, vb, k0);
+        PM_PV(vv, k0);
+      }
+    }
+#undef PM_PV
+#undef PM_K_SCORES
+#undef PM_KV_LOAD
+    PM_STAMP(6);
+    if (SELF && wave == 0 && ks == 0) {
+      const float p = sc[Lk - 1];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, qkv[128 + c * 8 + i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[i] += __shfl_xor(acc[i], 8, 64);
+      acc[i] += __shfl_xor(acc[i], 16, 64);
+      acc[i] += __shfl_xor(acc[i], 32, 64);
+    }
+    if (ks == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part[wave * 64 + c * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float o = 0.f;
+#pragma unroll
+      for (int w = 0; w < DF_WAVES; ++w) o += part[w * 64 + tid];
+      oval = o / sum;
     }
   }
-  if (SELF && wave == 0 && ks == 0) {
-    const float p = sc[Lk - 1];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, qkv[128 + c * 8 + i], acc[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    acc[i] += __shfl_xor(acc[i], 8, 64);
-    acc[i] += __shfl_xor(acc[i], 16, 64);
-    acc[i] += __shfl_xor(acc[i], 32, 64);
-  }
-  if (ks == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) part[wave * 64 + c * 8 + i] = acc[i];
-  }
-  __syncthreads();
   if (tid < 64) {
-    float o = 0.f;
+    if (CHAIN && Wo) qkv[tid] = oval;  // q is in registers, the new k / v rows were consumed in front of the barrier above
+    else out[((int64_t)b * H + h) * 64 + tid] = oval;
+  }
+  PM_STAMP(7);
+  if constexpr (CHAIN) {
+    if (!Wo) return;
+    __syncthreads();
+    float* my = hparts + (int64_t)blockIdx.x * d;
+    if constexpr (!WO_EARLY) {
 #pragma unroll
-    for (int w = 0; w < DF_WAVES; ++w) o += part[w * 64 + tid];
-    out[((int64_t)b * H + h) * 64 + tid] = o / sum;
+      for (int q = 0; q < NO; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int n = q * DF_THREADS + wave * 64 + i * 8 + (lane >> 3);
+          wo[q][i] = *(const bf16x8*)(Wo + (int64_t)(n < d ? n : d - 1) * inner + h * 64 + (lane & 7) * 8);
+        }
+    }
+    const f32x4 o0 = *(const f32x4*)(qkv + (lane & 7) * 8), o1 = *(const f32x4*)(qkv + (lane & 7) * 8 + 4);
+#pragma unroll
+    for (int q = 0; q < NO; ++q) {
+      float res = 0.f;
+#pragma unroll
+      for (int i = 0; i < (PM_CHAIN_ABL == 2 ? 1 : 8); ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = fmaf((float)wo[q][i][e], o0[e], a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = fmaf((float)wo[q][i][4 + e], o1[e], a);
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        res = (lane & 7) == i ? a : res;  // lane (g, c) keeps row i = c of its group g
+      }
+      const int n = q * DF_THREADS + wave * 64 + (lane & 7) * 8 + (lane >> 3);
+      if (n < d && (PM_CHAIN_ABL != 3 || res == 123.f)) my[n] = res;
+    }
+    PM_STAMP(8);
   }
 }
 
@@ -1314,15 +1633,17 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
  * in part order and applies bias / activation / residual.  split_ws: ceil(N / 16) * k_split * mt * 256 floats (mt = ceil(M / 16) rounded up to 1, 2 or 4);
  * split_cnt: ceil(N / 16) * 4 int32 (a ticket per feature tile and row tile), zero before the first launch and zero
  * again after every launch. */
-extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
-                                    const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
-                                    int act, int64_t k_split, float* split_ws, int32_t* split_cnt, void* stream) {
-  if (!x || !w || !out || !split_ws || !split_cnt || M <= 0 || N <= 0 || K <= 0) return PM_EINVAL;
+static int dec_linear_ksplit_impl(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                                  const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
+                                  int act, int64_t k_split, float* split_ws, int32_t* split_cnt, int mode, void* stream) {
+  if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return PM_EINVAL;
+  if (mode == DL_PLAIN && (!split_ws || !split_cnt)) return PM_EINVAL;
   if (M > 64 || K % 32) return PM_EUNSUPPORTED;
   if (k_split < 2 || k_split > 8 || K / 32 < k_split) return PM_EINVAL;
   if (ldx < K || ldw < K || ldx % 4 || ldw % 8) return PM_EALIGN;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)split_ws) & 15) return PM_EALIGN;
-  if (ldo < N || (resid && ldr < N)) return PM_EINVAL;
+  if (mode == DL_PARTS && ((((uintptr_t)out) & 15) || ldo % 4 || ldr % 4)) return PM_EALIGN;
+  if (ldo < N || (mode == DL_PLAIN && resid && ldr < N)) return PM_EINVAL;
   if (act != PM_ACT_NONE && act != PM_ACT_GELU && act != PM_ACT_GELU_TANH) return PM_EUNSUPPORTED;
   const int nwg = (int)((N + DL_FEATS - 1) / DL_FEATS);
   int mt = (int)((M + 15) / 16);
@@ -1340,16 +1661,16 @@ extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, 
   do {                                                                                                                \
     if (mt <= 1) hipLaunchKernelGGL((dec_linear_kernel<ACT_, 1, 1, NS_, false>), grid, dim3(256), 0, st, x, (int)ldx,   \
                                     (const float*)nullptr, (const float*)nullptr, 0.f, (const bf16*)w, ldw, bias, resid, \
-                                    (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, DL_PLAIN, (bf16*)nullptr,           \
+                                    (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)nullptr,           \
                                     (bf16*)nullptr, 0, 0, 0, (const int*)nullptr, split_ws, (int*)split_cnt, nwg);       \
     else if (mt == 2) hipLaunchKernelGGL((dec_linear_kernel<ACT_, 2, 1, NS_, false>), grid, dim3(256), 0, st, x,         \
                                          (int)ldx, (const float*)nullptr, (const float*)nullptr, 0.f, (const bf16*)w,    \
-                                         ldw, bias, resid, (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, DL_PLAIN,     \
+                                         ldw, bias, resid, (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, mode,     \
                                          (bf16*)nullptr, (bf16*)nullptr, 0, 0, 0, (const int*)nullptr, split_ws,          \
                                          (int*)split_cnt, nwg);                                                          \
     else hipLaunchKernelGGL((dec_linear_kernel<ACT_, 4, 1, 4, false>), grid, dim3(256), 0, st, x, (int)ldx,              \
                             (const float*)nullptr, (const float*)nullptr, 0.f, (const bf16*)w, ldw, bias, resid,         \
-                            (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, DL_PLAIN, (bf16*)nullptr, (bf16*)nullptr, 0, \
+                            (int)ldr, out, (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)nullptr, (bf16*)nullptr, 0, \
                             0, 0, (const int*)nullptr, split_ws, (int*)split_cnt, nwg);                                   \
   } while (0)
   rc = PM_OK;
@@ -1367,6 +1688,20 @@ extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, 
   if (rc != PM_OK) return rc;
   PM_CHECK_LAUNCH();
   return PM_OK;
+}
+
+extern "C" int pm_dec_linear_ksplit(const float* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                                    const float* resid, int64_t ldr, float* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
+                                    int act, int64_t k_split, float* split_ws, int32_t* split_cnt, void* stream) {
+  return dec_linear_ksplit_impl(x, ldx, w, ldw, bias, resid, ldr, out, ldo, M, N, K, act, k_split, split_ws, split_cnt, DL_PLAIN,
+                                stream);
+}
+
+extern "C" int pm_dec_linear_kparts(const float* x, int64_t ldx, const void* w, int64_t ldw, float* parts, int64_t ld_parts,
+                                    int64_t part_stride, int64_t M, int64_t N, int64_t K, int64_t k_split, void* stream) {
+  if (part_stride < M * ld_parts) return PM_EINVAL;
+  return dec_linear_ksplit_impl(x, ldx, w, ldw, nullptr, nullptr, part_stride, parts, ld_parts, M, N, K, PM_ACT_NONE, k_split,
+                                nullptr, nullptr, DL_PARTS, stream);
 }
 
 /* features per argmax tile for a given K (callers size ws_val / ws_idx as ceil(N / tile)) */
@@ -1387,23 +1722,28 @@ extern "C" int pm_dec_attention(const float* q, const void* kc, const void* vc, 
   return PM_OK;
 }
 
-template <typename KT>
+template <typename KT, bool CHAIN>
 static int dec_attention_fused_impl(const float* x, int64_t d, const float* gamma, const float* beta, float eps, const void* w,
                                     const float* bias, void* kc, void* vc, int64_t stride_b, int64_t stride_h, int64_t stride_k,
                                     const int32_t* pos_ptr, int64_t lk_const, int64_t lk_max, float* out, int64_t B, int64_t H,
-                                    int self_attn, void* stream) {
-  if (!x || !gamma || !beta || !w || !kc || !vc || !out || B <= 0 || H <= 0 || d <= 0 || lk_max <= 0) return PM_EINVAL;
+                                    int self_attn, const float* x_parts, int64_t n_parts, int64_t part_stride,
+                                    int64_t part_row_stride, const float* x_bias, float* x_out, const void* w_out,
+                                    float* head_parts, void* stream) {
+  if (!x || !gamma || !beta || !w || !kc || !vc || B <= 0 || H <= 0 || d <= 0 || lk_max <= 0) return PM_EINVAL;
+  if (w_out ? !head_parts : !out) return PM_EINVAL;
+  if (n_parts < 0 || n_parts > 64 || (n_parts > 0 && (!x_parts || !x_out || x_out == x))) return PM_EINVAL;
   if (d % 64 || d > 1280 || lk_max > DA_MAXK) return PM_EUNSUPPORTED;
   if (self_attn ? !pos_ptr : lk_const <= 0) return PM_EINVAL;
   if ((stride_b | stride_h | stride_k) % 8) return PM_EALIGN;
-  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)out) & 15) return PM_EALIGN;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)out | (uintptr_t)w_out) & 15) return PM_EALIGN;
   if (B * H > 0x7fffffff) return PM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nch = (int)(d / 64);
-#define PM_DF(SELF_, NCH_)                                                                                            \
-  hipLaunchKernelGGL((dec_attn_fused_kernel<SELF_, NCH_, KT>), dim3((unsigned)(B * H)), dim3(DF_THREADS), 0, st, x, (int)d, \
-                     gamma, beta, eps, (const bf16*)w, bias, (KT*)kc, (KT*)vc, stride_b, stride_h, stride_k,              \
-                     (const int*)pos_ptr, (int)lk_const, out, (int)H)
+#define PM_DF(SELF_, NCH_)                                                                                             \
+  hipLaunchKernelGGL((dec_attn_fused_kernel<SELF_, NCH_, KT, CHAIN>), dim3((unsigned)(B * H)), dim3(DF_THREADS), 0, st, x,  \
+                     (int)d, gamma, beta, eps, (const bf16*)w, bias, (KT*)kc, (KT*)vc, stride_b, stride_h, stride_k,      \
+                     (const int*)pos_ptr, (int)lk_const, out, (int)H, x_parts, (int)n_parts, part_stride, part_row_stride, \
+                     x_bias, x_out, (const bf16*)w_out, head_parts)
   if (self_attn) {
     if (nch <= 8) PM_DF(true, 8);
     else if (nch <= 12) PM_DF(true, 12);
@@ -1424,16 +1764,33 @@ extern "C" int pm_dec_attention_fused(const float* x, int64_t d, const float* ga
                                       const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
                                       int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
                                       int64_t lk_max, float* out, int64_t B, int64_t H, int self_attn, void* stream) {
-  return dec_attention_fused_impl<bf16>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr, lk_const,
-                                        lk_max, out, B, H, self_attn, stream);
+  return dec_attention_fused_impl<bf16, false>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr,
+                                               lk_const, lk_max, out, B, H, self_attn, nullptr, 0, 0, 0, nullptr, nullptr,
+                                               nullptr, nullptr, stream);
 }
 
 extern "C" int pm_dec_attention_fused_kv32(const float* x, int64_t d, const float* gamma, const float* beta, float eps,
                                            const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
                                            int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
                                            int64_t lk_max, float* out, int64_t B, int64_t H, int self_attn, void* stream) {
-  return dec_attention_fused_impl<float>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr, lk_const,
-                                         lk_max, out, B, H, self_attn, stream);
+  return dec_attention_fused_impl<float, false>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr,
+                                                lk_const, lk_max, out, B, H, self_attn, nullptr, 0, 0, 0, nullptr, nullptr,
+                                                nullptr, nullptr, stream);
+}
+
+extern "C" int pm_dec_attention_chain(const float* x, int64_t d, const float* gamma, const float* beta, float eps,
+                                      const void* w, const float* bias, void* kc, void* vc, int64_t stride_b,
+                                      int64_t stride_h, int64_t stride_k, const int32_t* pos_ptr, int64_t lk_const,
+                                      int64_t lk_max, int64_t B, int64_t H, int self_attn, int kv_f32, const float* x_parts,
+                                      int64_t n_parts, int64_t part_stride, int64_t part_row_stride, const float* x_bias,
+                                      float* x_out, const void* w_out, float* head_parts, float* out, void* stream) {
+  if (kv_f32)
+    return dec_attention_fused_impl<float, true>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr,
+                                                 lk_const, lk_max, out, B, H, self_attn, x_parts, n_parts, part_stride,
+                                                 part_row_stride, x_bias, x_out, w_out, head_parts, stream);
+  return dec_attention_fused_impl<bf16, true>(x, d, gamma, beta, eps, w, bias, kc, vc, stride_b, stride_h, stride_k, pos_ptr,
+                                              lk_const, lk_max, out, B, H, self_attn, x_parts, n_parts, part_stride,
+                                              part_row_stride, x_bias, x_out, w_out, head_parts, stream);
 }
 
 extern "C" int pm_dec_argmax_reduce(const float* ws_val, const int32_t* ws_idx, int64_t n_tiles, const int32_t* pos_ptr,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "pm_dec_linear_ksplit": ([_p, _l, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _l, _p, _p, _p], c_int),
     "pm_dec_attention_fused": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p], c_int),
     "pm_dec_attention_fused_kv32": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _p, _l, _l, _i, _p], c_int),
+    "pm_dec_attention_chain": ([_p, _l, _p, _p, _f, _p, _p, _p, _p, _l, _l, _l, _p, _l, _l, _l, _l, _i, _i, _p, _l, _l, _l, _p, _p, _p, _p, _p, _p], c_int),
+    "pm_dec_linear_kparts": ([_p, _l, _p, _l, _p, _l, _l, _l, _l, _l, _l, _p], c_int),
     "pm_dec_argmax_reduce": ([_p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _l, _p], c_int),
     "pm_dec_advance": ([_p, _p], c_int),
     "pm_dec_whisper_rules": ([_p, _l, _l, _p, _l, _p, _l, _l, _l, _l, _l, _p, _l, _p, _l, _l, _p], c_int),

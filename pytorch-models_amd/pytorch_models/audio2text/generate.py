@@ -172,6 +172,8 @@ class GreedyDecoder:
         self._embed0 = (L.pm_dec_embed, (self.tok_cur.data_ptr(), E.data_ptr(), pos_f32.data_ptr(), self.pos.data_ptr(),
                                          self.x.data_ptr(), B, d, V, None))
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.head_parts = self.x2 = self.fc2_parts = None
+        cur, oth, pending = self.x, None, None  # the residual stream's buffer; the other one; sums the next fused block must add
         self.self_k, self.self_v, self.cross_kv, self._cross_w = [], [], [], []
         for layer in dec.layers:
             if not layer.pre_norm:
@@ -193,23 +195,43 @@ class GreedyDecoder:
             env_fs = os.environ.get("PM_DEC_FUSE_SELF")
             fuse_self = fused and (B * H <= 256 if env_fs is None else env_fs != "0")
             fuse_cross = fused and os.environ.get("PM_DEC_FUSE_CROSS", "1") != "0"
+            # the chain of deferred sums (pm_dec_attention_chain): the self block leaves its output projection as per-head partial
+            # sums that the cross block adds while it loads its row, fc2 leaves its K parts to the next layer's self block - one
+            # launch and one ticket pass per layer less.  Needs both blocks fused (their workgroups own whole rows).
+            chain = (fuse_self and fuse_cross and ca is not None and not persistent and not v2
+                     and os.environ.get("PM_DEC_CHAIN", "1") != "0")
+            if chain and self.head_parts is None:
+                self.head_parts = torch.empty(B * H * d, **f32)
+                self.x2 = torch.empty(B, d, **f32)
+                oth = self.x2
             if persistent:
                 bo = _f32(sa.out_proj, "b", sa.out_proj.bias)
                 self._keep += [sa.out_proj.weight, bo]
                 ent = DecLayer(sa_g=g.data_ptr(), sa_b=b.data_ptr(), w_qkv=wqkv.data_ptr(), b_qkv=_ptr(bqkv), kc=kc.data_ptr(),
                                vc=vc.data_ptr(), w_so=sa.out_proj.weight.data_ptr(), b_so=_ptr(bo), sa_eps=float(layer.sa_norm.eps))
                 table.append(ent)
+            elif chain:
+                bo = _f32(sa.out_proj, "b", sa.out_proj.bias)
+                self._keep += [sa.out_proj.weight, bo]
+                n_in, p_in, ps_in, pr_in, pb_in = pending or (0, None, 0, 0, None)
+                add(L.pm_dec_attention_chain, cur.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
+                    wqkv.data_ptr(), _ptr(bqkv), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64, self.pos.data_ptr(),
+                    0, Tmax, B, H, 1, int(kv32), p_in, n_in, ps_in, pr_in, pb_in, oth.data_ptr() if n_in else None,
+                    sa.out_proj.weight.data_ptr(), self.head_parts.data_ptr(), None, None)
+                if n_in:
+                    cur, oth = oth, cur
+                pending = (H, self.head_parts.data_ptr(), d, H * d, _ptr(bo))
             elif fuse_self:  # LN + q/k/v projection + cache append + attention in one launch per layer
-                add(attn_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
+                add(attn_fused, cur.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.sa_norm.eps),
                     wqkv.data_ptr(), _ptr(bqkv), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64, self.pos.data_ptr(),
                     0, Tmax, self.att.data_ptr(), B, H, 1, None)
             else:
-                dec_linear(self.x, d, g, b, layer.sa_norm.eps, wqkv, bqkv, None, self.q, 3 * inner, mode=1, kc=kc, vc=vc)
+                dec_linear(cur, d, g, b, layer.sa_norm.eps, wqkv, bqkv, None, self.q, 3 * inner, mode=1, kc=kc, vc=vc)
                 add(L.pm_dec_attention, self.q.data_ptr(), kc.data_ptr(), vc.data_ptr(), H * Tmax * 64, Tmax * 64, 64,
                     self.pos.data_ptr(), 1, Tmax, self.att.data_ptr(), B, H, None)
-            if not persistent:
-                dec_linear(self.att, inner, None, None, 0.0, sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), self.x,
-                           self.x, d)
+            if not persistent and not chain:
+                dec_linear(self.att, inner, None, None, 0.0, sa.out_proj.weight, _f32(sa.out_proj, "b", sa.out_proj.bias), cur,
+                           cur, d)
             if ca is not None:
                 # cross attention: K/V of the memory projected ONCE (the reference re-projects them on every call,
                 # transformer.py:44-49), kept packed (B, S, [k | v]) in bf16
@@ -226,17 +248,25 @@ class GreedyDecoder:
                     ent.ca_g, ent.ca_b, ent.ca_eps = g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps)
                     ent.w_q, ent.b_q, ent.cross_kv = ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr()
                     ent.w_co, ent.b_co = ca.out_proj.weight.data_ptr(), _ptr(bo)
+                elif chain:  # x = the stream + the self block's projection (heads in order) + its bias, formed while loading
+                    n_in, p_in, ps_in, pr_in, pb_in = pending
+                    add(L.pm_dec_attention_chain, cur.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
+                        ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * kv_sz, S * 2 * inner, 64,
+                        2 * inner, None, S, S, B, H, 0, int(kv32), p_in, n_in, ps_in, pr_in, pb_in, oth.data_ptr(), None, None,
+                        self.att.data_ptr(), None)
+                    cur, oth = oth, cur
+                    pending = None
                 elif fuse_cross:
-                    add(attn_fused, self.x.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
+                    add(attn_fused, cur.data_ptr(), d, g.data_ptr(), b.data_ptr(), float(layer.ca_norm.eps),
                         ca.q_proj.weight.data_ptr(), _ptr(bq), kv.data_ptr(), kv.data_ptr() + inner * kv_sz, S * 2 * inner, 64,
                         2 * inner, None, S, S, self.att.data_ptr(), B, H, 0, None)
                 else:
-                    dec_linear(self.x, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, bq, None, self.q, inner)
+                    dec_linear(cur, d, g, b, layer.ca_norm.eps, ca.q_proj.weight, bq, None, self.q, inner)
                     add(L.pm_dec_attention, self.q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 2, S * 2 * inner, 64,
                         2 * inner, None, S, S, self.att.data_ptr(), B, H, None)
                 if not persistent:
-                    dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), self.x,
-                               self.x, d)
+                    dec_linear(self.att, inner, None, None, 0.0, ca.out_proj.weight, _f32(ca.out_proj, "b", ca.out_proj.bias), cur,
+                               cur, d)
             g, b = _f32(layer.mlp_norm, "g", layer.mlp_norm.weight), _f32(layer.mlp_norm, "b", layer.mlp_norm.bias)
             if mlp.act_name not in ("gelu", "approximate_gelu"):
                 raise NotImplementedError("greedy decode: GELU / tanh-GELU MLPs only")
@@ -250,10 +280,21 @@ class GreedyDecoder:
                 ent.mlp_g, ent.mlp_b, ent.mlp_eps = g.data_ptr(), b.data_ptr(), float(layer.mlp_norm.eps)
                 ent.w1, ent.b1, ent.w2, ent.b2 = mlp.linear1.weight.data_ptr(), _ptr(b1), mlp.linear2.weight.data_ptr(), _ptr(b2)
                 continue
-            dec_linear(self.x, d, g, b, layer.mlp_norm.eps, mlp.linear1.weight, _f32(mlp.linear1, "b", mlp.linear1.bias), None,
+            dec_linear(cur, d, g, b, layer.mlp_norm.eps, mlp.linear1.weight, _f32(mlp.linear1, "b", mlp.linear1.bias), None,
                        self.h[:, :hid], hid, act=act_code)
-            dec_linear(self.h[:, :hid], hid, None, None, 0.0, mlp.linear2.weight, _f32(mlp.linear2, "b", mlp.linear2.bias),
-                       self.x, self.x, d)
+            ksp = max(2, min(int(os.environ.get("PM_DEC_KSPLIT", "4")), 8, hid // 32))
+            if chain and layer is not dec.layers[-1] and hid >= ks_min and int(os.environ.get("PM_DEC_KSPLIT", "4")) > 1:
+                # fc2's K parts stay parts: the next layer's self block adds them (with the bias and this stream) while it loads
+                if self.fc2_parts is None:
+                    self.fc2_parts = torch.empty(8, B, d, **f32)
+                b2 = _f32(mlp.linear2, "b", mlp.linear2.bias)
+                self._keep += [mlp.linear2.weight, b2]
+                add(L.pm_dec_linear_kparts, self.h.data_ptr(), self.h.stride(0), mlp.linear2.weight.data_ptr(),
+                    mlp.linear2.weight.stride(0), self.fc2_parts.data_ptr(), d, B * d, B, d, hid, ksp, None)
+                pending = (ksp, self.fc2_parts.data_ptr(), B * d, d, _ptr(b2))
+            else:
+                dec_linear(self.h[:, :hid], hid, None, None, 0.0, mlp.linear2.weight, _f32(mlp.linear2, "b", mlp.linear2.bias),
+                           cur, cur, d)
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
         if persistent:
             import ctypes
@@ -273,11 +314,11 @@ class GreedyDecoder:
         if not 1 <= topk <= 64:
             raise ValueError("greedy decode: topk must be in 1..64")
         self.topk = topk
-        xl, gl, bl = self.x, g, b
+        xl, gl, bl = cur, g, b  # (the chain leaves the stream in x or x2; the next step's row always goes to x)
         if self.split_final_norm:
             self.xn = torch.empty(B, d, **f32)
             self._keep += [g, b]
-            add(L.pm_layernorm, self.x.data_ptr(), d, 1, g.data_ptr(), b.data_ptr(), float(dec.norm.eps), self.xn.data_ptr(), d, 1,
+            add(L.pm_layernorm, cur.data_ptr(), d, 1, g.data_ptr(), b.data_ptr(), float(dec.norm.eps), self.xn.data_ptr(), d, 1,
                 B, d, None)
             xl, gl, bl = self.xn, None, None
         if topk == 1 and rules is None:

@@ -98,6 +98,99 @@ def test_dec_attention(ops, B, H, T, lk):
     torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,d,T,pos,self_attn,kv32,n_in", [(4, 8, 512, 40, 17, 1, 0, 4), (32, 8, 512, 1500, 0, 0, 0, 8), (3, 6, 384, 24, 0, 1, 1, 0),
+                                                             (2, 20, 1280, 1500, 0, 0, 0, 20), (5, 12, 768, 64, 63, 1, 0, 3), (2, 8, 512, 200, 0, 0, 1, 8)])
+def test_dec_attention_chain_defers_the_sums_without_changing_them(B, H, d, T, pos, self_attn, kv32, n_in):
+    """pm_dec_attention_chain: IN - the row it builds (x + bias + parts in part order) is bit for bit the row a combining pass
+    would have written, and the attention on it is pm_dec_attention_fused's bit for bit; OUT - the per-head partial sums of the
+    output projection add up to att W_o^T."""
+    from pytorch_models._hip import check, lib
+
+    L = lib()
+    inner = H * 64
+    kdt = torch.float32 if kv32 else torch.bfloat16
+    x0 = synth_input("ab_x", (B, d), 31).cuda()
+    g, be = (1 + 0.1 * synth_input("ab_g", (d,), 32)).cuda(), (0.1 * synth_input("ab_b", (d,), 33)).cuda()
+    nq = 3 if self_attn else 1
+    w = bf(synth_input("ab_w", (nq * inner, d), 34, scale=d ** -0.5)).cuda()
+    bias = (0.1 * synth_input("ab_bias", (nq * inner,), 35)).cuda()
+    wo = bf(synth_input("ab_wo", (d, inner), 36, scale=inner ** -0.5)).cuda()
+    xb = (0.1 * synth_input("ab_bo", (d,), 37)).cuda()
+    kc0 = synth_input("ab_k", (B, H, T, 64), 38).to(kdt).cuda()
+    vc0 = synth_input("ab_v", (B, H, T, 64), 39).to(kdt).cuda()
+    parts = synth_input("ab_parts", (max(n_in, 1), B, d), 40).cuda()
+    posv = torch.tensor([pos], dtype=torch.int32, device="cuda")
+    pp = posv.data_ptr() if self_attn else None
+    lk = 0 if self_attn else T
+    fused = L.pm_dec_attention_fused_kv32 if kv32 else L.pm_dec_attention_fused
+    # the row a combining pass writes: parts in order, then the bias, then the stream (dec_linear_kernel's epilogue order)
+    xin = x0.clone()
+    if n_in:
+        sp = torch.zeros_like(x0)
+        for p in range(n_in):
+            sp = sp + parts[p]
+        xin = (sp + xb) + x0
+    att = torch.empty(B, inner, device="cuda")
+    kc, vc = kc0.clone(), vc0.clone()
+    check(fused(xin.data_ptr(), d, g.data_ptr(), be.data_ptr(), 1e-5, w.data_ptr(), bias.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                H * T * 64, T * 64, 64, pp, lk, T, att.data_ptr(), B, H, self_attn, None), "fused")
+    # the fused block itself against fp64: LayerNorm -> projection(s) -> softmax(q K^T / 8) V per head
+    xn = torch.nn.functional.layer_norm(xin.double(), (d,), g.double(), be.double(), 1e-5)
+    qkv = xn @ w.double().T + bias.double()
+    q = qkv[:, :inner].view(B, H, 1, 64)
+    kd, vd = kc0.double(), vc0.double()
+    if self_attn:
+        kd, vd = kd[:, :, : pos + 1].clone(), vd[:, :, : pos + 1].clone()
+        kd[:, :, pos] = qkv[:, inner : 2 * inner].view(B, H, 64).to(kdt).double()
+        vd[:, :, pos] = qkv[:, 2 * inner :].view(B, H, 64).to(kdt).double()
+    ref = (torch.softmax(q @ kd.transpose(-1, -2) / 8.0, -1) @ vd).reshape(B, inner)
+    torch.testing.assert_close(att.double(), ref, rtol=2e-5, atol=2e-5)
+    for emit in (0, 1):
+        xout = torch.full((B, d), float("nan"), device="cuda")
+        att2 = torch.full((B, inner), float("nan"), device="cuda")
+        hp = torch.full((B, H, d), float("nan"), device="cuda")
+        kc2, vc2 = kc0.clone(), vc0.clone()
+        check(L.pm_dec_attention_chain(x0.data_ptr(), d, g.data_ptr(), be.data_ptr(), 1e-5, w.data_ptr(), bias.data_ptr(),
+                                       kc2.data_ptr(), vc2.data_ptr(), H * T * 64, T * 64, 64, pp, lk, T, B, H, self_attn, kv32,
+                                       parts.data_ptr() if n_in else None, n_in, B * d, d, xb.data_ptr() if n_in else None,
+                                       xout.data_ptr() if n_in else None, wo.data_ptr() if emit else None,
+                                       hp.data_ptr() if emit else None, None if emit else att2.data_ptr(), None), "chain")
+        torch.cuda.synchronize()
+        assert torch.equal(kc2, kc) and torch.equal(vc2, vc)  # rows appended at `pos`: the same bits
+        if n_in:
+            assert torch.equal(xout, xin)
+        if emit:
+            torch.testing.assert_close(hp.double().sum(1), att.double() @ wo.double().T, rtol=1e-5, atol=1e-5)
+        else:
+            assert torch.equal(att2, att)
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(32, 512, 2048, 4), (2, 384, 1536, 2), (33, 64, 2048, 3), (64, 100, 512, 4), (32, 1280, 5120, 8)])
+def test_dec_linear_kparts_are_the_k_split_kernels_parts(M, N, K, ks):
+    """parts (in order) + bias + residual == pm_dec_linear_ksplit's output bit for bit: deferring the sum to the consumer changes
+    no rounding."""
+    from pytorch_models._hip import check, lib
+
+    L = lib()
+    x = synth_input("kp_x", (M, K), 3).cuda()
+    w = bf(synth_input("kp_w", (N, K), 4, scale=K ** -0.5)).cuda()
+    bias, resid = synth_input("kp_b", (N,), 5).cuda(), synth_input("kp_r", (M, N), 6).cuda()
+    ld = (N + 3) // 4 * 4
+    parts = torch.full((ks, M, ld), float("nan"), device="cuda")
+    check(L.pm_dec_linear_kparts(x.data_ptr(), K, w.data_ptr(), K, parts.data_ptr(), ld, M * ld, M, N, K, ks, None), "kparts")
+    mt = (M + 15) // 16
+    mt = 1 if mt <= 1 else 2 if mt == 2 else 4
+    ws = torch.empty(((N + 15) // 16) * ks * mt * 256, device="cuda")
+    cnt = torch.zeros(((N + 15) // 16) * 4, dtype=torch.int32, device="cuda")
+    want = torch.empty(M, N, device="cuda")
+    check(L.pm_dec_linear_ksplit(x.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), resid.data_ptr(), N, want.data_ptr(), N, M, N, K, 0,
+                                 ks, ws.data_ptr(), cnt.data_ptr(), None), "ksplit")
+    sp = torch.zeros(M, N, device="cuda")
+    for p in range(ks):
+        sp = sp + parts[p, :, :N]
+    assert torch.equal((sp + bias) + resid, want)
+
+
 def _setup(tag, seed, B):
     from pytorch_models.audio2text import Whisper, WhisperPreprocessor
 
