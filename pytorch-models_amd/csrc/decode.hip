@@ -720,12 +720,6 @@ constexpr int DF_THREADS = 512, DF_WAVES = 8;
 #ifndef PM_CROSS_DB
 #define PM_CROSS_DB 1
 #endif
-#ifndef PM_CROSS_ONEPASS
-#define PM_CROSS_ONEPASS 0  // measured: 25.3 us per cross block against 22.9 for the two-pass form (profiles/r03)
-#endif
-#ifndef PM_CROSS_NKU1
-#define PM_CROSS_NKU1 4  // keys per lane group and step of the one-pass form (K + V: 2 x NKU1 x 16 B per lane and register set)
-#endif
 // In-kernel phase stamps of the fused attention block (variant builds only: tools/build_variant.sh stamps -DPM_DF_STAMPS=1;
 // tools/chain_stamps.py reads them through pm_debug_df_stamps)
 #ifndef PM_DF_STAMPS
@@ -860,8 +854,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   }
   // ---- the K stream does not depend on q: request its first NKU passes now - AFTER the projection weights, so the
   // weights are not queued behind it - and let HBM stream while the LayerNorm and the projection run.
-  constexpr bool ONEPASS = !SELF && PM_CROSS_ONEPASS;  // K and V together, online softmax per lane group: see "one pass" below
-  constexpr int NKU = SELF ? 4 : ONEPASS ? (sizeof(KT) == 4 ? 2 : PM_CROSS_NKU1) : PM_CROSS_NKU;
+  constexpr int NKU = SELF ? 4 : PM_CROSS_NKU;
   const int c = lane & 7, ks = lane >> 3;
   const KT* kb = Kc + b * sb + h * sh + c * 8;
   const KT* vb = Vc + b * sb + h * sh + c * 8;
@@ -872,15 +865,6 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     int key = u * 64 + wave * 8 + ks;
     key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
     kv[u] = SELF ? *(const kv8*)(kb + key * sk) : __builtin_nontemporal_load((const kv8*)(kb + key * sk));
-  }
-  kv8 vv[NKU];
-  if constexpr (ONEPASS) {
-#pragma unroll
-    for (int u = 0; u < NKU; ++u) {
-      int key = u * 64 + wave * 8 + ks;
-      key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-      vv[u] = __builtin_nontemporal_load((const kv8*)(vb + key * sk));
-    }
   }
   if constexpr (CHAIN) {
     if (np > 0) {
@@ -988,229 +972,130 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       }
     }
   }
-  if constexpr (ONEPASS) {
-    // ---- one pass (the cross block): K and V of a key group are requested together and used together, every lane group (8 lanes =
-    // one key at a time, 64 lane groups per workgroup) keeps its own running maximum, sum and 8-wide accumulator, rescaled once
-    // per group of NKU keys; the 64 states are merged at the end (wave: shuffles, workgroup: LDS), in a fixed order.  Against the
-    // two-pass form (scores -> workgroup softmax -> P.V) the stream never stops: no score array, no barriers between the first
-    // key and the last, and the 2.4 us of softmax reductions between the passes (stamps: 5.1 K + 2.4 + 3.5 V of 16.6 us) are gone.
-    PM_STAMP(3);
-    const f32x4 q0 = *(const f32x4*)(qkv + c * 8), q1 = *(const f32x4*)(qkv + c * 8 + 4);
-    constexpr int KG = 64 * NKU;
-    float acc[8], m_run = -INFINITY, l_run = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  // ---- scores.  The cross block's 1500 keys are six groups of NKU x 64: the NEXT group is requested before this one is used
+  // (two register sets, the loop unrolled by two), so that 32-64 KB per CU stay in flight across the group boundary - with the
+  // request and its use in the same iteration every group exposed one full memory latency (PM_CROSS_DB=0 builds that form)
+  const f32x4 q0 = *(const f32x4*)(qkv + c * 8), q1 = *(const f32x4*)(qkv + c * 8 + 4);
+  constexpr int KG = 64 * NKU;
 #define PM_KV_LOAD(dst_, base_, k0_)                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
-      int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                         \
-      key_ = key_ < Lc ? key_ : Lc - 1;                                                                                  \
-      dst_[u] = __builtin_nontemporal_load((const kv8*)(base_ + key_ * sk));                                             \
-    }
-#define PM_ONE_STEP(k_, v_, k0_)                                                                                       \
-    {                                                                                                                    \
-      float sv_[NKU], mg_ = -INFINITY;                                                                                   \
-      _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                  \
-        float t_ = 0.f;                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) t_ = fmaf(q0[i], (float)k_[u][i], t_);                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) t_ = fmaf(q1[i], (float)k_[u][4 + i], t_);                         \
-        t_ += __shfl_xor(t_, 1, 64);                                                                                     \
-        t_ += __shfl_xor(t_, 2, 64);                                                                                     \
-        t_ += __shfl_xor(t_, 4, 64);                                                                                     \
-        sv_[u] = (k0_) + u * 64 + wave * 8 + ks < Lc ? t_ * 0.125f : -INFINITY;                                          \
-        mg_ = fmaxf(mg_, sv_[u]);                                                                                        \
-      }                                                                                                                  \
-      const float mn_ = fmaxf(m_run, mg_);                                                                               \
-      if (mn_ > -INFINITY) { /* (a lane group whose keys all lie beyond Lc so far has nothing to add) */               \
-        const float f_ = expf(m_run - mn_);                                                                              \
-        l_run *= f_;                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] *= f_;                                                      \
-        _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                \
-          const float p_ = expf(sv_[u] - mn_);                                                                           \
-          l_run += p_;                                                                                                   \
-          _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] = fmaf(p_, (float)v_[u][i], acc[i]);                      \
-        }                                                                                                                \
-        m_run = mn_;                                                                                                     \
-      }                                                                                                                  \
-    }
-    {
-      kv8 kw[NKU], vw[NKU];
-      for (int k0 = 0; k0 < Lc;) {
-        if (k0 + KG < Lc) { PM_KV_LOAD(kw, kb, k0 + KG); PM_KV_LOAD(vw, vb, k0 + KG); }
-        PM_ONE_STEP(kv, vv, k0);
-        k0 += KG;
-        if (k0 >= Lc) break;
-        if (k0 + KG < Lc) { PM_KV_LOAD(kv, kb, k0 + KG); PM_KV_LOAD(vv, vb, k0 + KG); }
-        PM_ONE_STEP(kw, vw, k0);
-        k0 += KG;
-      }
-    }
-#undef PM_ONE_STEP
-#undef PM_KV_LOAD
-    PM_STAMP(6);
-    {  // merge: the 8 lane groups of the wave (lanes xor 8, 16, 32), then the 8 waves through LDS
-      float mw = m_run;
-      mw = fmaxf(mw, __shfl_xor(mw, 8, 64));
-      mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
-      mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
-      const float f = m_run > -INFINITY ? expf(m_run - mw) : 0.f;
-      float lw = l_run * f;
-      lw += __shfl_xor(lw, 8, 64);
-      lw += __shfl_xor(lw, 16, 64);
-      lw += __shfl_xor(lw, 32, 64);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float a = acc[i] * f;
-        a += __shfl_xor(a, 8, 64);
-        a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
-        acc[i] = a;
-      }
-      if (ks == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) part[wave * 64 + c * 8 + i] = acc[i];
-      }
-      if (lane == 0) { scratch[2 * DF_WAVES + wave] = mw; scratch[3 * DF_WAVES + wave] = lw; }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      float mall = scratch[2 * DF_WAVES];
-#pragma unroll
-      for (int w = 1; w < DF_WAVES; ++w) mall = fmaxf(mall, scratch[2 * DF_WAVES + w]);
-      float o = 0.f, lsum = 0.f;
-#pragma unroll
-      for (int w = 0; w < DF_WAVES; ++w) {
-        const float mwv = scratch[2 * DF_WAVES + w];
-        const float fw = mwv > -INFINITY ? expf(mwv - mall) : 0.f;
-        o = fmaf(part[w * 64 + tid], fw, o);
-        lsum = fmaf(scratch[3 * DF_WAVES + w], fw, lsum);
-      }
-      oval = o / lsum;
+  _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
+    int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                         \
+    key_ = key_ < Lc ? key_ : Lc - 1;                                                                                  \
+    dst_[u] = SELF ? *(const kv8*)(base_ + key_ * sk) : __builtin_nontemporal_load((const kv8*)(base_ + key_ * sk));    \
+  }
+#define PM_K_SCORES(src_, k0_)                                                                                         \
+  _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
+    float sv = 0.f;                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], (float)src_[u][i], sv);                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], (float)src_[u][4 + i], sv);                         \
+    sv += __shfl_xor(sv, 1, 64);                                                                                       \
+    sv += __shfl_xor(sv, 2, 64);                                                                                       \
+    sv += __shfl_xor(sv, 4, 64);                                                                                       \
+    const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
+    if (c == 0 && key_ < Lc) sc[key_] = sv * 0.125f;                                                                   \
+  }
+  if constexpr (!SELF && PM_CROSS_DB) {
+    kv8 kw[NKU];
+    for (int k0 = 0; k0 < Lc;) {
+      if (k0 + KG < Lc) PM_KV_LOAD(kw, kb, k0 + KG);
+      PM_K_SCORES(kv, k0);
+      k0 += KG;
+      if (k0 >= Lc) break;
+      if (k0 + KG < Lc) PM_KV_LOAD(kv, kb, k0 + KG);
+      PM_K_SCORES(kw, k0);
+      k0 += KG;
     }
   } else {
-    // ---- scores.  The cross block's 1500 keys are six groups of NKU x 64: the NEXT group is requested before this one is used
-    // (two register sets, the loop unrolled by two), so that 32-64 KB per CU stay in flight across the group boundary - with the
-    // request and its use in the same iteration every group exposed one full memory latency (PM_CROSS_DB=0 builds that form)
-    const f32x4 q0 = *(const f32x4*)(qkv + c * 8), q1 = *(const f32x4*)(qkv + c * 8 + 4);
-    constexpr int KG = 64 * NKU;
-#define PM_KV_LOAD(dst_, base_, k0_)                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
-      int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                         \
-      key_ = key_ < Lc ? key_ : Lc - 1;                                                                                  \
-      dst_[u] = SELF ? *(const kv8*)(base_ + key_ * sk) : __builtin_nontemporal_load((const kv8*)(base_ + key_ * sk));    \
+    for (int k0 = 0; k0 < Lc; k0 += KG) {
+      if (k0 > 0) PM_KV_LOAD(kv, kb, k0);
+      PM_K_SCORES(kv, k0);
     }
-#define PM_K_SCORES(src_, k0_)                                                                                         \
-    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
-      float sv = 0.f;                                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], (float)src_[u][i], sv);                             \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], (float)src_[u][4 + i], sv);                         \
-      sv += __shfl_xor(sv, 1, 64);                                                                                       \
-      sv += __shfl_xor(sv, 2, 64);                                                                                       \
-      sv += __shfl_xor(sv, 4, 64);                                                                                       \
-      const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
-      if (c == 0 && key_ < Lc) sc[key_] = sv * 0.125f;                                                                   \
-    }
-    if constexpr (!SELF && PM_CROSS_DB) {
-      kv8 kw[NKU];
-      for (int k0 = 0; k0 < Lc;) {
-        if (k0 + KG < Lc) PM_KV_LOAD(kw, kb, k0 + KG);
-        PM_K_SCORES(kv, k0);
-        k0 += KG;
-        if (k0 >= Lc) break;
-        if (k0 + KG < Lc) PM_KV_LOAD(kv, kb, k0 + KG);
-        PM_K_SCORES(kw, k0);
-        k0 += KG;
-      }
-    } else {
-      for (int k0 = 0; k0 < Lc; k0 += KG) {
-        if (k0 > 0) PM_KV_LOAD(kv, kb, k0);
-        PM_K_SCORES(kv, k0);
-      }
-    }
-    if (SELF && tid < 8) {  // the new key (position t), same summation shape as above
-      float sv = 0.f;
+  }
+  if (SELF && tid < 8) {  // the new key (position t), same summation shape as above
+    float sv = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], qkv[64 + c * 8 + i], sv);
+    for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], qkv[64 + c * 8 + i], sv);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], qkv[64 + c * 8 + 4 + i], sv);
-      sv += __shfl_xor(sv, 1, 64);
-      sv += __shfl_xor(sv, 2, 64);
-      sv += __shfl_xor(sv, 4, 64);
-      if (c == 0) sc[Lk - 1] = sv * 0.125f;
-    }
-    PM_STAMP(4);
-    // V does not depend on the scores: request the first NKU passes now, so they fly during the softmax reductions
+    for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], qkv[64 + c * 8 + 4 + i], sv);
+    sv += __shfl_xor(sv, 1, 64);
+    sv += __shfl_xor(sv, 2, 64);
+    sv += __shfl_xor(sv, 4, 64);
+    if (c == 0) sc[Lk - 1] = sv * 0.125f;
+  }
+  PM_STAMP(4);
+  // V does not depend on the scores: request the first NKU passes now, so they fly during the softmax reductions
+  kv8 vv[NKU];
 #pragma unroll
-    for (int u = 0; u < NKU; ++u) {
-      int key = u * 64 + wave * 8 + ks;
-      key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
-      vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
-    }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int k = tid; k < Lk; k += DF_THREADS) mx = fmaxf(mx, sc[k]);
-    mx = block_reduce8(mx, scratch + 2 * DF_WAVES, true);
-    float sum = 0.f;
-    for (int k = tid; k < Lk; k += DF_THREADS) {
-      const float p = expf(sc[k] - mx);
-      sc[k] = p;
-      sum += p;
-    }
-    sum = block_reduce8(sum, scratch + 3 * DF_WAVES, false);  // its barrier also publishes the p values
+  for (int u = 0; u < NKU; ++u) {
+    int key = u * 64 + wave * 8 + ks;
+    key = key < Lc ? key : (Lc > 0 ? Lc - 1 : 0);
+    vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int k = tid; k < Lk; k += DF_THREADS) mx = fmaxf(mx, sc[k]);
+  mx = block_reduce8(mx, scratch + 2 * DF_WAVES, true);
+  float sum = 0.f;
+  for (int k = tid; k < Lk; k += DF_THREADS) {
+    const float p = expf(sc[k] - mx);
+    sc[k] = p;
+    sum += p;
+  }
+  sum = block_reduce8(sum, scratch + 3 * DF_WAVES, false);  // its barrier also publishes the p values
 
-    PM_STAMP(5);
-    // ---- P.V
-    float acc[8];
+  PM_STAMP(5);
+  // ---- P.V
+  float acc[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #define PM_PV(src_, k0_)                                                                                               \
-    _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
-      const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
-      const float p_ = key_ < Lc ? sc[key_] : 0.f;                                                                       \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] = fmaf(p_, (float)src_[u][i], acc[i]);                        \
+  _Pragma("unroll") for (int u = 0; u < NKU; ++u) {                                                                    \
+    const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
+    const float p_ = key_ < Lc ? sc[key_] : 0.f;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] = fmaf(p_, (float)src_[u][i], acc[i]);                        \
+  }
+  if constexpr (!SELF && PM_CROSS_DB) {
+    kv8 vw[NKU];
+    for (int k0 = 0; k0 < Lc;) {
+      if (k0 + KG < Lc) PM_KV_LOAD(vw, vb, k0 + KG);
+      PM_PV(vv, k0);
+      k0 += KG;
+      if (k0 >= Lc) break;
+      if (k0 + KG < Lc) PM_KV_LOAD(vv, vb, k0 + KG);
+      PM_PV(vw, k0);
+      k0 += KG;
     }
-    if constexpr (!SELF && PM_CROSS_DB) {
-      kv8 vw[NKU];
-      for (int k0 = 0; k0 < Lc;) {
-        if (k0 + KG < Lc) PM_KV_LOAD(vw, vb, k0 + KG);
-        PM_PV(vv, k0);
-        k0 += KG;
-        if (k0 >= Lc) break;
-        if (k0 + KG < Lc) PM_KV_LOAD(vv, vb, k0 + KG);
-        PM_PV(vw, k0);
-        k0 += KG;
-      }
-    } else {
-      for (int k0 = 0; k0 < Lc; k0 += KG) {
-        if (k0 > 0) PM_KV_LOAD(vv, vb, k0);
-        PM_PV(vv, k0);
-      }
+  } else {
+    for (int k0 = 0; k0 < Lc; k0 += KG) {
+      if (k0 > 0) PM_KV_LOAD(vv, vb, k0);
+      PM_PV(vv, k0);
     }
+  }
 #undef PM_PV
 #undef PM_K_SCORES
 #undef PM_KV_LOAD
-    PM_STAMP(6);
-    if (SELF && wave == 0 && ks == 0) {
-      const float p = sc[Lk - 1];
+  PM_STAMP(6);
+  if (SELF && wave == 0 && ks == 0) {
+    const float p = sc[Lk - 1];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, qkv[128 + c * 8 + i], acc[i]);
-    }
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, qkv[128 + c * 8 + i], acc[i]);
+  }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      acc[i] += __shfl_xor(acc[i], 8, 64);
-      acc[i] += __shfl_xor(acc[i], 16, 64);
-      acc[i] += __shfl_xor(acc[i], 32, 64);
-    }
-    if (ks == 0) {
+  for (int i = 0; i < 8; ++i) {
+    acc[i] += __shfl_xor(acc[i], 8, 64);
+    acc[i] += __shfl_xor(acc[i], 16, 64);
+    acc[i] += __shfl_xor(acc[i], 32, 64);
+  }
+  if (ks == 0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) part[wave * 64 + c * 8 + i] = acc[i];
-    }
-    __syncthreads();
-    if (tid < 64) {
-      float o = 0.f;
+    for (int i = 0; i < 8; ++i) part[wave * 64 + c * 8 + i] = acc[i];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float o = 0.f;
 #pragma unroll
-      for (int w = 0; w < DF_WAVES; ++w) o += part[w * 64 + tid];
-      oval = o / sum;
-    }
+    for (int w = 0; w < DF_WAVES; ++w) o += part[w * 64 + tid];
+    oval = o / sum;
   }
   if (tid < 64) {
     if (CHAIN && Wo) qkv[tid] = oval;  // q is in registers, the new k / v rows were consumed in front of the barrier above
