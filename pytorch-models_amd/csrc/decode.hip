@@ -409,6 +409,30 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
       xv[u][t][1] = *(const f32x4*)(xr + 4);
     }
   }
+  // ---- vocabulary tiles: inner step q = (tile, half): 32 weight rows.  The first step's rows are requested HERE, right behind x
+  // (loads return in order: x first) and in front of the LayerNorm, whose barriers no load crosses: requested behind it
+  // the kernel's first microseconds moved no weight bytes
+  const int total = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x * halves;  // inner steps of this workgroup
+  const int tile_feats = halves * 32;
+  auto wrow_ptr = [&](int q, int f) {
+    const int tile = blockIdx.x + (q / halves) * gridDim.x, hs = q - (q / halves) * halves;
+    int n = tile * tile_feats + hs * 32 + f * 16 + fi;
+    n = n < N ? n : N - 1;
+    return W + (int64_t)n * ldw + kq * 8;
+  };
+  bf16x8 a[NSTEP][2], an[NSTEP][2];
+  if (total > 0) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const bf16* wp = wrow_ptr(0, f);
+#pragma unroll
+      for (int u = 0; u < NSTEP; ++u) {
+        int s = wave + 4 * u;
+        s = s < ksteps ? s : ksteps - 1;
+        a[u][f] = *(const bf16x8*)(wp + s * 32);
+      }
+    }
+  }
   for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
   float mean[MT], rstd[MT];
 #pragma unroll
@@ -471,28 +495,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
     }
   }
 
-  // ---- vocabulary tiles: inner step q = (tile, half): 32 weight rows
-  const int total = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x * halves;  // inner steps of this workgroup
-  const int tile_feats = halves * 32;
-  auto wrow_ptr = [&](int q, int f) {
-    const int tile = blockIdx.x + (q / halves) * gridDim.x, hs = q - (q / halves) * halves;
-    int n = tile * tile_feats + hs * 32 + f * 16 + fi;
-    n = n < N ? n : N - 1;
-    return W + (int64_t)n * ldw + kq * 8;
-  };
-  bf16x8 a[NSTEP][2], an[NSTEP][2];
-  if (total > 0) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const bf16* wp = wrow_ptr(0, f);
-#pragma unroll
-      for (int u = 0; u < NSTEP; ++u) {
-        int s = wave + 4 * u;
-        s = s < ksteps ? s : ksteps - 1;
-        a[u][f] = *(const bf16x8*)(wp + s * 32);
-      }
-    }
-  }
+  // ---- vocabulary tiles (set up in front of the LayerNorm: the first step's weight rows are already on their way)
   float best_v[MT];
   int best_i[MT];
 #pragma unroll
