@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from pytorch_models._hip import check, lib  # noqa: E402
 
 L = lib()
-B, H, d, S, T, pos = 32, 8, 512, 1500, 228, 120
+B, H, d, S, T, pos = int(os.environ.get("CB_B", "32")), int(os.environ.get("CB_H", "8")), int(os.environ.get("CB_D", "512")), 1500, 228, 120
 inner = H * 64
 torch.manual_seed(0)
 dev = "cuda"

@@ -9,13 +9,13 @@ import torch  # noqa: E402
 from pytorch_models._hip import check, lib  # noqa: E402
 
 L = lib()
-d, H, S = 512, 8, 1500
+d, H, S = int(os.environ.get("CB_D", "512")), int(os.environ.get("CB_H", "8")), 1500
 torch.manual_seed(0)
 g = torch.ones(d, device="cuda")
 be = torch.zeros(d, device="cuda")
 w = (torch.randn(d, d, device="cuda") / d ** 0.5).to(torch.bfloat16)
 LAYOUT = sys.argv[1] if len(sys.argv) > 1 else "token"
-for B in (8, 16, 24, 32, 48, 64):
+for B in ([int(os.environ["CB_B"])] if "CB_B" in os.environ else (8, 16, 24, 32, 48, 64)):
     x = torch.randn(B, d, device="cuda")
     kv = torch.randn(B, S, 2 * d, device="cuda").to(torch.bfloat16)
     out = torch.empty(B, d, device="cuda")
