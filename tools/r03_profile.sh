@@ -11,7 +11,7 @@ kt() {  # name, then bench.py arguments (the program itself behind "--": no env 
   local name=$1; shift
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$name -- python3 bench.py "$@" --steps 10 --warmup 3 --no-cpu-baseline --no-exact > $out/kt_$name.log 2>&1 || echo "kernel trace $name failed"
   cp $(find $out/kt_$name -name "*kernel_stats.csv" | head -1) $out/bench_${name}_kernel_stats.csv 2>/dev/null
-  tail -1 $out/kt_$name.log > $out/bench_${name}_line_under_rocprof.json
+  grep "^{\"metric\"" $out/kt_$name.log | tail -1 > $out/bench_${name}_line_under_rocprof.json
 }
 echo "kernel traces"
 kt vit_default --workload vit
