@@ -5,7 +5,7 @@ step's last kernel).  Units / gfx950 correction as tools/collect_traffic.py (KiB
     python tools/collect_step_traffic.py OUT/f OUT/w profiles/r02/whisper_step_traffic.json"""
 import csv, glob, json, sys
 
-DEC = ("dec_linear_kernel", "dec_attn_fused_kernel", "dec_attn_kernel", "dec_argmax_reduce_kernel", "dec_embed_kernel", "dec_layers_kernel",
+DEC = ("dec_linear_kernel", "dec_logits_kernel", "dec_attn_fused_kernel", "dec_attn_kernel", "dec_argmax_reduce_kernel", "dec_embed_kernel", "dec_layers_kernel",
        "dec_attn_v2_kernel")
 LAST = "dec_argmax_reduce_kernel"
 
