@@ -378,17 +378,23 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
 // step's MFMAs, partial sums of the four waves (each owns every fourth K step, as in dec_linear_kernel) through a double-buffered
 // LDS area - one barrier per step, wave 0 reduces step s while everyone computes s + 1.  Every sum is formed in
 // dec_linear_kernel's order, so the logits and the (max, index) pairs are bit-identical to that kernel's.
-template <int MT>
-__global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+// NW waves share a row's K steps (wave w: steps w, w + NW, ...), NF 16-feature tiles per inner step.  <4, 2>: two 256-thread
+// workgroups per CU (round 2).  <8, 4> (round 3, the default): ONE 512-thread workgroup per CU - the x rows are loaded,
+// normalised and split once per CU instead of twice (stamps: 8.3 of the kernel's 20 us went by before its first MFMA, 128 KB of
+// x and ~2.3 us of VALU per CU), a step is a whole 64-feature arg-max tile.
+template <int MT, int NW, int NF>
+__global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
                                                          const bf16* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias, int M, int N, int K,
                                                          float* __restrict__ ws_val, int* __restrict__ ws_idx, int ntiles,
                                                          int halves) {
-  constexpr int NSTEP = 4, GBK = 128 * NSTEP;
-  __shared__ float part[4 * 64];
+  constexpr int NSTEP = 16 / NW, GBK = 512;  // K <= 512: at most 16 K steps of 32
+  __shared__ float part[NW * 64];
   __shared__ float gb[2 * GBK];
-  __shared__ __attribute__((aligned(16))) float red[2][4 * 2 * MT * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float red[2][NW * NF * MT * 64 * 4];
+  __shared__ float tbv[2][NF][MT * 16];  // NW == 8: per step and feature tile, the rows' (max, index)
+  __shared__ int tbi[2][NF][MT * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fi = lane & 15, kq = lane >> 4;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
   f32x4 xv[NSTEP][MT][2];
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
-    int s = wave + 4 * u;
+    int s = wave + NW * u;
     s = s < ksteps ? s : ksteps - 1;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -413,34 +419,39 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
   // (loads return in order: x first) and in front of the LayerNorm, whose barriers no load crosses: requested behind it
   // the kernel's first microseconds moved no weight bytes
   const int total = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x * halves;  // inner steps of this workgroup
-  const int tile_feats = halves * 32;
+  const int tile_feats = halves * 16 * NF;
   auto wrow_ptr = [&](int q, int f) {
     const int tile = blockIdx.x + (q / halves) * gridDim.x, hs = q - (q / halves) * halves;
-    int n = tile * tile_feats + hs * 32 + f * 16 + fi;
+    int n = tile * tile_feats + hs * 16 * NF + f * 16 + fi;
     n = n < N ? n : N - 1;
     return W + (int64_t)n * ldw + kq * 8;
   };
-  bf16x8 a[NSTEP][2], an[NSTEP][2];
+  bf16x8 a[NSTEP][NF], an[NSTEP][NF];
   if (total > 0) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < NF; ++f) {
       const bf16* wp = wrow_ptr(0, f);
 #pragma unroll
       for (int u = 0; u < NSTEP; ++u) {
-        int s = wave + 4 * u;
+        int s = wave + NW * u;
         s = s < ksteps ? s : ksteps - 1;
         a[u][f] = *(const bf16x8*)(wp + s * 32);
       }
     }
   }
-  for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
+  for (int k = tid; k < K; k += 64 * NW) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
+  auto part_sum = [&](int r) {  // over the waves, pairwise (NW = 4: the order of the 4-wave kernels)
+    float h0 = (part[r] + part[64 + r]) + (part[128 + r] + part[192 + r]);
+    if constexpr (NW == 8) h0 += (part[256 + r] + part[320 + r]) + (part[384 + r] + part[448 + r]);
+    return h0;
+  };
   float mean[MT], rstd[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     float sm = 0.f;
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u)
-      if (wave + 4 * u < ksteps) {
+      if (wave + NW * u < ksteps) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sm += xv[u][t][0][i] + xv[u][t][1][i];
       }
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int r = t * 16 + fi;
-    mean[t] = ((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K;
+    mean[t] = part_sum(r) / (float)K;
   }
   __syncthreads();
 #pragma unroll
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
     float q = 0.f;
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u)
-      if (wave + 4 * u < ksteps) {
+      if (wave + NW * u < ksteps) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float d0 = xv[u][t][0][i] - mean[t], d1 = xv[u][t][1][i] - mean[t];
@@ -476,12 +487,12 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int r = t * 16 + fi;
-    rstd[t] = rsqrtf(((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K + eps);
+    rstd[t] = rsqrtf(part_sum(r) / (float)K + eps);
   }
   bf16x8 xh[NSTEP][MT], xm[NSTEP][MT], xl[NSTEP][MT];
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
-    int s = wave + 4 * u;
+    int s = wave + NW * u;
     s = s < ksteps ? s : ksteps - 1;
     const int k0 = s * 32 + kq * 8;
 #pragma unroll
@@ -504,28 +515,28 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
   for (int q = 0; q < total; ++q) {
     if (q + 1 < total) {  // the next step's weight rows fly during this step's MFMAs
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
+      for (int f = 0; f < NF; ++f) {
         const bf16* wp = wrow_ptr(q + 1, f);
 #pragma unroll
         for (int u = 0; u < NSTEP; ++u) {
-          int s = wave + 4 * u;
+          int s = wave + NW * u;
           s = s < ksteps ? s : ksteps - 1;
           an[u][f] = *(const bf16x8*)(wp + s * 32);
         }
       }
     }
-    f32x4 acc[2][MT];
+    f32x4 acc[NF][MT];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int t = 0; t < MT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u) {
-      if (wave + 4 * u >= ksteps) break;
+      if (wave + NW * u >= ksteps) break;
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < NF; ++f) {
           acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], xh[u][t], acc[f][t], 0, 0, 0);
           acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], xm[u][t], acc[f][t], 0, 0, 0);
           acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], xl[u][t], acc[f][t], 0, 0, 0);
@@ -533,20 +544,65 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
     }
     float* rb = red[q & 1];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int t = 0; t < MT; ++t) *(f32x4*)(rb + (((wave * 2 + f) * MT + t) * 64 + lane) * 4) = acc[f][t];
+      for (int t = 0; t < MT; ++t) *(f32x4*)(rb + (((wave * NF + f) * MT + t) * 64 + lane) * 4) = acc[f][t];
     lds_barrier();  // (not __syncthreads: the next step's weight loads stay in flight)
+    if constexpr (NW == 8) {
+      // the step is a whole arg-max tile: wave f < NF adds the 8 waves' partial sums of feature tile f and leaves its rows'
+      // (max, index); wave 0 picks the tile's winner among the NF one step later (behind that step's barrier) - one wave
+      // adding all 64 partial tiles of a step (the <4, 2> form's way) left the other seven waiting at the next barrier
+      if (wave == 0 && q > 0) {
+        const int tile = blockIdx.x + (q - 1) * gridDim.x;
+        if (lane < MT * 16 && lane < M) {
+          float bv = tbv[(q - 1) & 1][0][lane];
+          int bi = tbi[(q - 1) & 1][0][lane];
+#pragma unroll
+          for (int f = 1; f < NF; ++f) {
+            const float ov = tbv[(q - 1) & 1][f][lane];
+            if (ov > bv) { bv = ov; bi = tbi[(q - 1) & 1][f][lane]; }  // ascending features: strict > keeps the lowest index
+          }
+          ws_val[(int64_t)lane * ntiles + tile] = bv;
+          ws_idx[(int64_t)lane * ntiles + tile] = bi;
+        }
+      }
+      if (wave < NF) {
+        const int tile = blockIdx.x + q * gridDim.x, f = wave;
+        const int n = tile * tile_feats + f * 16 + kq * 4;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = *(const f32x4*)(rb + (((0 * NF + f) * MT + t) * 64 + lane) * 4);
+#pragma unroll
+          for (int w = 1; w < NW; ++w) v += *(const f32x4*)(rb + (((w * NF + f) * MT + t) * 64 + lane) * 4);
+          float bv = -INFINITY;
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int nn = n + r;
+            if (nn >= N) continue;
+            const float e = v[r] + (bias ? bias[nn] : 0.f);
+            if (e > bv) { bv = e; bi = nn; }
+          }
+#pragma unroll
+          for (int o = 16; o < 64; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+          }
+          if (kq == 0) { tbv[q & 1][f][t * 16 + fi] = bv; tbi[q & 1][f][t * 16 + fi] = bi; }
+        }
+      }
+    } else
     if (wave == 0) {
       const int tile = blockIdx.x + (q / halves) * gridDim.x, hs = q - (q / halves) * halves;
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const int n = tile * tile_feats + hs * 32 + f * 16 + kq * 4;
+      for (int f = 0; f < NF; ++f) {
+        const int n = tile * tile_feats + hs * 16 * NF + f * 16 + kq * 4;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-          f32x4 v = *(const f32x4*)(rb + (((0 * 2 + f) * MT + t) * 64 + lane) * 4);
+          f32x4 v = *(const f32x4*)(rb + (((0 * NF + f) * MT + t) * 64 + lane) * 4);
 #pragma unroll
-          for (int w = 1; w < 4; ++w) v += *(const f32x4*)(rb + (((w * 2 + f) * MT + t) * 64 + lane) * 4);
+          for (int w = 1; w < NW; ++w) v += *(const f32x4*)(rb + (((w * NF + f) * MT + t) * 64 + lane) * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int nn = n + r;
@@ -580,7 +636,24 @@ __global__ __launch_bounds__(256) void dec_logits_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u)
 #pragma unroll
-      for (int f = 0; f < 2; ++f) a[u][f] = an[u][f];
+      for (int f = 0; f < NF; ++f) a[u][f] = an[u][f];
+  }
+  if constexpr (NW == 8) {
+    if (total > 0) {  // the last tile's winner
+      lds_barrier();
+      if (wave == 0 && lane < MT * 16 && lane < M) {
+        const int q = total - 1, tile = blockIdx.x + q * gridDim.x;
+        float bv = tbv[q & 1][0][lane];
+        int bi = tbi[q & 1][0][lane];
+#pragma unroll
+        for (int f = 1; f < NF; ++f) {
+          const float ov = tbv[q & 1][f][lane];
+          if (ov > bv) { bv = ov; bi = tbi[q & 1][f][lane]; }
+        }
+        ws_val[(int64_t)lane * ntiles + tile] = bv;
+        ws_idx[(int64_t)lane * ntiles + tile] = bi;
+      }
+    }
   }
 }
 
@@ -1484,13 +1557,26 @@ extern "C" int pm_dec_linear(const float* x, int64_t ldx, const float* gamma, co
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
       return n;
     }();
-    const int grid = nwg < 2 * cus ? nwg : 2 * cus;
-    if (mt <= 1)
-      hipLaunchKernelGGL((dec_logits_kernel<1>), dim3(grid), dim3(256), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias,
-                         (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, ft / 2);
-    else
-      hipLaunchKernelGGL((dec_logits_kernel<2>), dim3(grid), dim3(256), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias,
-                         (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, ft / 2);
+    // one 512-thread workgroup per CU whose step is a whole 64-feature tile (PM_DEC_LOGITS_WAVES=4: two 256-thread workgroups
+    // per CU, 32 features per step)
+    static const int lw = [] { const char* e = getenv("PM_DEC_LOGITS_WAVES"); return e ? atoi(e) : 8; }();
+    if (lw == 8 && ft == 4) {
+      const int grid = nwg < cus ? nwg : cus;
+      if (mt <= 1)
+        hipLaunchKernelGGL((dec_logits_kernel<1, 8, 4>), dim3(grid), dim3(512), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw,
+                           bias, (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, 1);
+      else
+        hipLaunchKernelGGL((dec_logits_kernel<2, 8, 4>), dim3(grid), dim3(512), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw,
+                           bias, (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, 1);
+    } else {
+      const int grid = nwg < 2 * cus ? nwg : 2 * cus;
+      if (mt <= 1)
+        hipLaunchKernelGGL((dec_logits_kernel<1, 4, 2>), dim3(grid), dim3(256), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw,
+                           bias, (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, ft / 2);
+      else
+        hipLaunchKernelGGL((dec_logits_kernel<2, 4, 2>), dim3(grid), dim3(256), 0, st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw,
+                           bias, (int)M, (int)N, (int)K, ws_val, (int*)ws_idx, nwg, ft / 2);
+    }
   } else if (mode == DL_ARGMAX && ft == 2)
     rc = dl_launch<PM_ACT_NONE, 2>(mt, dim3(nwg), st, x, (int)ldx, gamma, beta, eps, (const bf16*)w, ldw, bias, resid, (int)ldr, out,
                               (int)ldo, (int)M, (int)N, (int)K, mode, (bf16*)kcache, (bf16*)vcache, (int)inner, (int)H,
