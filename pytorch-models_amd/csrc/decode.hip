@@ -819,10 +819,45 @@ extern "C" int pm_debug_df_stamps(void* out) {
 #define PM_CHAIN_ABL 0  // ablation builds of the chain's OUT side (tools/chain_bench.py): 1 no W_o loads, 2 one row of eight, 3 no store
 #endif
 
+// Cross-lane exchanges of the fused attention block as DPP modifiers of the add / max itself (v_add_f32 ... quad_perm / row_ror
+// / row_half_mirror) wherever the partner lane sits in the same row of 16: hipcc turns EVERY __shfl_xor into ds_bpermute_b32
+// - an LDS round trip of ~100 cycles - and this block's critical path is a chain of them (two LayerNorm reductions, the
+// projection's 8-lane sums, the scores' 8-lane sums, the softmax's max and sum: ~33 dependent exchanges, ~1.4 us of a
+// 10 us block).  Only the last two steps of a whole-wave reduction (partners 16 and 32 lanes away) still go through LDS.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// lane i + lane i ^ 1, ^ 2 (quad permutes), ^ 4 (mirror of the half row: the other quad's sum, uniform by then): every lane of
+// an aligned group of 8 gets the group's sum, added in the order of the xor butterfly (same bits)
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ float xor8_dpp(float v) { return dpp_mov<0x128>(v); }  // row_ror:8 = lane i ^ 8
+__device__ __forceinline__ float dwave_sum(float v) {
+  v = sum8_dpp(v);
+  v += xor8_dpp(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float dwave_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, xor8_dpp(v));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
 // Block-wide sum / max over 8 waves through ONE barrier: every call site owns its 8-float slot of the scratch array, so
 // no barrier is needed to protect the slot's previous use (the kernel runs each reduction once).
 __device__ __forceinline__ float block_reduce8(float v, float* slot, bool is_max) {
-  v = is_max ? wave_max(v) : wave_sum(v);
+  v = is_max ? dwave_max(v) : dwave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) slot[wave] = v;
   __syncthreads();
@@ -1017,9 +1052,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[UPFRONT ? o : 0][i][e], xp[e], acc);
       }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
+    acc = sum8_dpp(acc);
     if (pl == 0) {
       float v = acc + bpe[o];
       if (SELF && o > 0) {  // cached k / v: round once to the cache's type (bf16; float = no rounding), store, use the stored value
@@ -1064,9 +1097,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     float sv = 0.f;                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], (float)src_[u][i], sv);                             \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], (float)src_[u][4 + i], sv);                         \
-    sv += __shfl_xor(sv, 1, 64);                                                                                       \
-    sv += __shfl_xor(sv, 2, 64);                                                                                       \
-    sv += __shfl_xor(sv, 4, 64);                                                                                       \
+    sv = sum8_dpp(sv);                                                                                                 \
     const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
     if (c == 0 && key_ < Lc) sc[key_] = sv * 0.125f;                                                                   \
   }
@@ -1093,9 +1124,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     for (int i = 0; i < 4; ++i) sv = fmaf(q0[i], qkv[64 + c * 8 + i], sv);
 #pragma unroll
     for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], qkv[64 + c * 8 + 4 + i], sv);
-    sv += __shfl_xor(sv, 1, 64);
-    sv += __shfl_xor(sv, 2, 64);
-    sv += __shfl_xor(sv, 4, 64);
+    sv = sum8_dpp(sv);
     if (c == 0) sc[Lk - 1] = sv * 0.125f;
   }
   PM_STAMP(4);
@@ -1158,7 +1187,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    acc[i] += __shfl_xor(acc[i], 8, 64);
+    acc[i] += xor8_dpp(acc[i]);
     acc[i] += __shfl_xor(acc[i], 16, 64);
     acc[i] += __shfl_xor(acc[i], 32, 64);
   }
@@ -1202,9 +1231,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
         for (int e = 0; e < 4; ++e) a = fmaf((float)wo[q][i][e], o0[e], a);
 #pragma unroll
         for (int e = 0; e < 4; ++e) a = fmaf((float)wo[q][i][4 + e], o1[e], a);
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
-        a += __shfl_xor(a, 4, 64);
+        a = sum8_dpp(a);
         res = (lane & 7) == i ? a : res;  // lane (g, c) keeps row i = c of its group g
       }
       const int n = q * DF_THREADS + wave * 64 + (lane & 7) * 8 + (lane >> 3);
