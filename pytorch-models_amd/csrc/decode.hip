@@ -27,6 +27,73 @@ namespace {
 
 constexpr int DL_FEATS = 16;  // output features per workgroup
 
+// Cross-lane exchanges of the fused attention block as DPP modifiers of the add / max itself (v_add_f32 ... quad_perm / row_ror
+// / row_half_mirror) wherever the partner lane sits in the same row of 16: hipcc turns EVERY __shfl_xor into ds_bpermute_b32
+// - an LDS round trip of ~100 cycles - and this block's critical path is a chain of them (two LayerNorm reductions, the
+// projection's 8-lane sums, the scores' 8-lane sums, the softmax's max and sum: ~33 dependent exchanges, ~1.4 us of a
+// 10 us block).  Partners 16 and 32 lanes away: gfx950's v_permlane16_swap / v_permlane32_swap (one vector-ALU instruction
+// each: with both operands the same value the two results are a lane's own value and its partner's).  No exchange of the step's
+// kernels goes through LDS any more.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// lane i + lane i ^ 1, ^ 2 (quad permutes), ^ 4 (mirror of the half row: the other quad's sum, uniform by then): every lane of
+// an aligned group of 8 gets the group's sum, added in the order of the xor butterfly (same bits)
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ float xor8_dpp(float v) { return dpp_mov<0x128>(v); }  // row_ror:8 = lane i ^ 8
+// v[i] (+ | max) v[i ^ 16] and v[i ^ 32]: a + b and max(a, b) do not care which of the two results is the lane's own
+__device__ __forceinline__ float add_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float max_xor16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// the better of a lane's (value, index) pair and its partner's 16 / 32 lanes away (higher value, lower index on a tie)
+template <int O>
+__device__ __forceinline__ void argmax_xor(float& bv, int& bi) {
+  static_assert(O == 16 || O == 32, "partners in another row of 16");
+  const auto rv = O == 16 ? __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false)
+                          : __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+  const auto ri = O == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false)
+                          : __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+  const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+  const int i0 = (int)ri[0], i1 = (int)ri[1];
+  const bool second = v1 > v0 || (v1 == v0 && i1 < i0);
+  bv = second ? v1 : v0;
+  bi = second ? i1 : i0;
+}
+__device__ __forceinline__ float dwave_sum(float v) {
+  v = sum8_dpp(v);
+  v += xor8_dpp(v);
+  v = add_xor16(v);
+  return add_xor32(v);
+}
+__device__ __forceinline__ float dwave_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, xor8_dpp(v));
+  v = max_xor16(v);
+  return max_xor32(v);
+}
+
+
 __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -175,8 +242,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) sm += xv[u][t][0][i] + xv[u][t][1][i];
           }
-        sm += __shfl_xor(sm, 16, 64);
-        sm += __shfl_xor(sm, 32, 64);
+        sm = add_xor16(sm);
+        sm = add_xor32(sm);
         if (kq == 0) part[wave * 64 + t * 16 + fi] = sm;
       }
       lds_barrier();
@@ -199,8 +266,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
               q = fmaf(d1, d1, q);
             }
           }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
+        q = add_xor16(q);
+        q = add_xor32(q);
         if (kq == 0) part[wave * 64 + t * 16 + fi] = q;
       }
       lds_barrier();
@@ -354,12 +421,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
     for (int t = 0; t < MT; ++t) {
       float bv = best_v[t];
       int bi = best_i[t];
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {  // the 4 lanes sharing a sequence (kq = 0..3)
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
+      argmax_xor<16>(bv, bi);  // the 4 lanes sharing a sequence (kq = 0..3)
+      argmax_xor<32>(bv, bi);
       const int row = rbase + t * 16 + fi;
       if (kq == 0 && row < M) {
         ws_val[(int64_t)row * nwg + blockIdx.x] = bv;
@@ -455,8 +518,8 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) sm += xv[u][t][0][i] + xv[u][t][1][i];
       }
-    sm += __shfl_xor(sm, 16, 64);
-    sm += __shfl_xor(sm, 32, 64);
+    sm = add_xor16(sm);
+    sm = add_xor32(sm);
     if (kq == 0) part[wave * 64 + t * 16 + fi] = sm;
   }
   __syncthreads();
@@ -479,8 +542,8 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
           q = fmaf(d1, d1, q);
         }
       }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
+    q = add_xor16(q);
+    q = add_xor32(q);
     if (kq == 0) part[wave * 64 + t * 16 + fi] = q;
   }
   __syncthreads();
@@ -583,12 +646,8 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
             const float e = v[r] + (bias ? bias[nn] : 0.f);
             if (e > bv) { bv = e; bi = nn; }
           }
-#pragma unroll
-          for (int o = 16; o < 64; o <<= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-          }
+          argmax_xor<16>(bv, bi);  // the 4 lanes sharing a sequence (kq = 0..3)
+          argmax_xor<32>(bv, bi);
           if (kq == 0) { tbv[q & 1][f][t * 16 + fi] = bv; tbi[q & 1][f][t * 16 + fi] = bi; }
         }
       }
@@ -617,12 +676,8 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
         for (int t = 0; t < MT; ++t) {
           float bv = best_v[t];
           int bi = best_i[t];
-#pragma unroll
-          for (int o = 16; o < 64; o <<= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-          }
+          argmax_xor<16>(bv, bi);  // the 4 lanes sharing a sequence (kq = 0..3)
+          argmax_xor<32>(bv, bi);
           const int row = t * 16 + fi;
           if (kq == 0 && row < M) {
             ws_val[(int64_t)row * ntiles + tile] = bv;
@@ -724,9 +779,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
       for (int i = 0; i < 4; ++i) s = fmaf(q0[i], (float)kv[u][i], s);
 #pragma unroll
       for (int i = 0; i < 4; ++i) s = fmaf(q1[i], (float)kv[u][4 + i], s);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
+      s = sum8_dpp(s);
       const int key = k0 + u * 32 + wave * 8 + ks;
       if (c == 0 && key < Lk) sc[key] = s * 0.125f;
     }
@@ -764,9 +817,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    acc[i] += __shfl_xor(acc[i], 8, 64);
-    acc[i] += __shfl_xor(acc[i], 16, 64);
-    acc[i] += __shfl_xor(acc[i], 32, 64);
+    acc[i] += xor8_dpp(acc[i]);
+    acc[i] = add_xor16(acc[i]);
+    acc[i] = add_xor32(acc[i]);
   }
   if (ks == 0) {
 #pragma unroll
@@ -818,41 +871,6 @@ extern "C" int pm_debug_df_stamps(void* out) {
 #ifndef PM_CHAIN_ABL
 #define PM_CHAIN_ABL 0  // ablation builds of the chain's OUT side (tools/chain_bench.py): 1 no W_o loads, 2 one row of eight, 3 no store
 #endif
-
-// Cross-lane exchanges of the fused attention block as DPP modifiers of the add / max itself (v_add_f32 ... quad_perm / row_ror
-// / row_half_mirror) wherever the partner lane sits in the same row of 16: hipcc turns EVERY __shfl_xor into ds_bpermute_b32
-// - an LDS round trip of ~100 cycles - and this block's critical path is a chain of them (two LayerNorm reductions, the
-// projection's 8-lane sums, the scores' 8-lane sums, the softmax's max and sum: ~33 dependent exchanges, ~1.4 us of a
-// 10 us block).  Only the last two steps of a whole-wave reduction (partners 16 and 32 lanes away) still go through LDS.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// lane i + lane i ^ 1, ^ 2 (quad permutes), ^ 4 (mirror of the half row: the other quad's sum, uniform by then): every lane of
-// an aligned group of 8 gets the group's sum, added in the order of the xor butterfly (same bits)
-__device__ __forceinline__ float sum8_dpp(float v) {
-  v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
-  v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
-  v += dpp_mov<0x141>(v);  // row_half_mirror
-  return v;
-}
-__device__ __forceinline__ float xor8_dpp(float v) { return dpp_mov<0x128>(v); }  // row_ror:8 = lane i ^ 8
-__device__ __forceinline__ float dwave_sum(float v) {
-  v = sum8_dpp(v);
-  v += xor8_dpp(v);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
-__device__ __forceinline__ float dwave_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  v = fmaxf(v, xor8_dpp(v));
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
-}
 
 // Block-wide sum / max over 8 waves through ONE barrier: every call site owns its 8-float slot of the scratch array, so
 // no barrier is needed to protect the slot's previous use (the kernel runs each reduction once).
@@ -1188,8 +1206,8 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     acc[i] += xor8_dpp(acc[i]);
-    acc[i] += __shfl_xor(acc[i], 16, 64);
-    acc[i] += __shfl_xor(acc[i], 32, 64);
+    acc[i] = add_xor16(acc[i]);
+    acc[i] = add_xor32(acc[i]);
   }
   if (ks == 0) {
 #pragma unroll
@@ -1274,13 +1292,31 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
     if (v > bv || (v == bv && ix < bi)) { second = fmaxf(second, bv); bv = v; bi = ix; }
     else second = fmaxf(second, v);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(bv, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    const float o2 = __shfl_xor(second, o, 64);
+  // (winner, runner-up) over the wave: partners 1, 2 lanes away by quad permutes, 4 by the half row's mirror (the quads are
+  // uniform by then), 8 by a row rotate, 16 / 32 by v_permlane16 / 32_swap - no LDS round trips (see dpp_mov)
+  auto comb = [&](float ov, int oi, float o2) {
     if (ov > bv || (ov == bv && oi < bi)) { second = fmaxf(fmaxf(second, o2), bv); bv = ov; bi = oi; }
     else second = fmaxf(fmaxf(second, o2), ov);
+  };
+#define PM_AR_DPP(C_) comb(dpp_mov<C_>(bv), __builtin_amdgcn_update_dpp(0, bi, C_, 0xf, 0xf, true), dpp_mov<C_>(second))
+  PM_AR_DPP(0xB1);
+  PM_AR_DPP(0x4E);
+  PM_AR_DPP(0x141);
+  PM_AR_DPP(0x128);
+#undef PM_AR_DPP
+  {
+    const auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    const auto ri = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+    const auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(second), __float_as_uint(second), false, false);
+    const int sel = (lane & 16) ? 0 : 1;  // the partner's copy: result 1 in even rows of 16, result 0 in odd rows
+    comb(__uint_as_float(rv[sel]), (int)ri[sel], __uint_as_float(r2[sel]));
+  }
+  {
+    const auto rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    const auto ri = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(second), __float_as_uint(second), false, false);
+    const int sel = (lane & 32) ? 0 : 1;
+    comb(__uint_as_float(rv[sel]), (int)ri[sel], __uint_as_float(r2[sel]));
   }
   if (lane == 0) { sv[wave] = bv; si[wave] = bi; s2[wave] = second; }
   __syncthreads();
