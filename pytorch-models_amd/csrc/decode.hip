@@ -117,6 +117,26 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// In-kernel phase stamps of the fused attention block (variant builds only: tools/build_variant.sh stamps -DPM_DF_STAMPS=1;
+// tools/chain_stamps.py reads them through pm_debug_df_stamps)
+#ifndef PM_DF_STAMPS
+#define PM_DF_STAMPS 0
+#endif
+#if PM_DF_STAMPS
+__device__ unsigned long long g_df_stamps[1024 * 16];
+#define PM_STAMP(i_)                                                                                  \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_df_stamps[blockIdx.x * 16 + (i_)] = wall_clock64();  \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+extern "C" int pm_debug_df_stamps(void* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_df_stamps), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : 1;
+}
+#else
+#define PM_STAMP(i_)
+#endif
+
 // NSTEP = K steps of 32 per wave held in registers at once.  LayerNorm kernels (K = d_model) keep the wave's WHOLE
 // share of x in registers: the row statistics come from those registers (two exchanges through LDS: mean, then the
 // centred second moment - the reference's two-pass form), so x is read from memory exactly once and every load of the
@@ -136,6 +156,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
   __shared__ float gb[LN ? 2 * GBK : 2];
   __shared__ __attribute__((aligned(16))) float red[4 * FT * MT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
+  PM_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * (DL_FEATS * FT);
   const int fi = lane & 15, kq = lane >> 4;
@@ -229,7 +250,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
       }
       __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // every load of the trip is REQUESTED before the first is used: without this pin hipcc fuses the request loop with the
+      // compute loop below (whose steps end in a conditional break) and sinks each K step's loads to their use - four dependent
+      // memory round trips per trip instead of one (seen in the ISA: load x, load w, wait, 3 MFMAs, branch, load ...)
+      __builtin_amdgcn_sched_barrier(0);
     }
+    PM_STAMP(1);
     float mean[MT], rstd[MT];
     if constexpr (LN) {
       // ---- mean: lane partial over its elements, then over the 4 kq lanes, then over the 4 waves through LDS
@@ -277,9 +304,20 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         rstd[t] = rsqrtf(((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r])) / (float)K + eps);
       }
     }
+    PM_STAMP(2);
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u) {
-      if (sb + 4 * u >= ks1) break;
+      // NO branch around a K step this wave does not own (K not a multiple of 128 NSTEP): its activations become zeros by a
+      // select and its MFMAs add nothing.  With `break` here hipcc sank every step's loads into the step's guarded block -
+      // load x, load w, wait, 3 MFMAs, branch, load ...: four dependent memory round trips per launch instead of one (ISA of
+      // dec_linear_kernel<0, 1, 1, 4, false>, the out_proj / fc2 launches of the decode step)
+      // Only the small instantiations (12 load registers sets: the decode step's plain projections at 16 rows x 16 features):
+      // at d = 1280 the request-everything-first form needs the registers the occupancy lives on (fc2 part 15.8 -> 21.8 us)
+      constexpr bool NOBR = !LN && NSTEP * (2 * MT + FT) <= 12;
+      const bool valid = sb + 4 * u < ks1;
+      if constexpr (!NOBR) {
+        if (!valid) break;
+      }
       const int k0 = (sb + 4 * u) * 32 + kq * 8;
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -289,6 +327,10 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         if constexpr (LN) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gb[k0 + i] + gb[GBK + k0 + i];
+        }
+        if constexpr (NOBR) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = valid ? v[i] : 0.f;
         }
         bf16x8 hi, mid, lo;
         split3(v, hi, mid, lo);
@@ -301,12 +343,14 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
       }
     }
   }
+  PM_STAMP(3);
 #pragma unroll
   for (int f = 0; f < FT; ++f)
 #pragma unroll
     for (int t = 0; t < MT; ++t) *(f32x4*)(red + (((wave * FT + f) * MT + t) * 64 + lane) * 4) = acc[f][t];
   __syncthreads();
   if (wave != 0) return;
+  PM_STAMP(4);
 
   // D[row = feature 4*kq + r][col = sequence fi]; partial sums added in wave order 0..3
   float best_v[MT];
@@ -341,6 +385,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         }
       }
     }
+    PM_STAMP(5);
     return;
   }
   if (kparts > 1) {
@@ -416,6 +461,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
       }
     }
   }
+  PM_STAMP(5);
   if (mode == DL_ARGMAX) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -848,25 +894,6 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 constexpr int DF_THREADS = 512, DF_WAVES = 8;
 #ifndef PM_CROSS_DB
 #define PM_CROSS_DB 1
-#endif
-// In-kernel phase stamps of the fused attention block (variant builds only: tools/build_variant.sh stamps -DPM_DF_STAMPS=1;
-// tools/chain_stamps.py reads them through pm_debug_df_stamps)
-#ifndef PM_DF_STAMPS
-#define PM_DF_STAMPS 0
-#endif
-#if PM_DF_STAMPS
-__device__ unsigned long long g_df_stamps[1024 * 16];
-#define PM_STAMP(i_)                                                                                  \
-  do {                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) g_df_stamps[blockIdx.x * 16 + (i_)] = wall_clock64();  \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-  } while (0)
-extern "C" int pm_debug_df_stamps(void* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_df_stamps), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : 1;
-}
-#else
-#define PM_STAMP(i_)
 #endif
 #ifndef PM_CHAIN_ABL
 #define PM_CHAIN_ABL 0  // ablation builds of the chain's OUT side (tools/chain_bench.py): 1 no W_o loads, 2 one row of eight, 3 no store
