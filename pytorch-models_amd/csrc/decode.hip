@@ -969,15 +969,22 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   constexpr int XI = CHAIN ? (NCH * 64 + DF_THREADS - 1) / DF_THREADS : 1;  // row elements per thread of this instantiation
   float xb[XI], pv[8][XI];
   if constexpr (CHAIN) {
-    const float* pr = xparts + (int64_t)b * xprow;
+    // BRANCH-FREE requests (clamped indices, a readable stand-in row where there are no parts): written as
+    // `cond ? load : 0` hipcc put each load in a block of its own and sank the first addition of the sum into the first
+    // part's block - `global_load; s_waitcnt vmcnt(0); v_add` right here, i.e. the row, the bias and part 0 waited for
+    // BEFORE the remaining parts, the weights and the K stream were even requested (the +1 us of the IN side)
+    const bool has = np > 0;
+    const float* pr = has ? xparts + (int64_t)b * xprow : xr;
+    const float* bsrc = (has && xbias) ? xbias : xr;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int k = tid + i * DF_THREADS;
-      xb[i] = (np > 0 && xbias && k < d) ? xbias[k] : 0.f;
+      const int kc = k < d ? k : d - 1;
+      xb[i] = bsrc[kc];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int pp = j < np ? j : np - 1;
-        pv[j][i] = (np > 0 && k < d) ? pr[pp * xpstride + k] : 0.f;
+        const int pp = j < np ? j : (has ? np - 1 : 0);
+        pv[j][i] = pr[pp * xpstride + kc];
       }
     }
   }
@@ -1042,7 +1049,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
 #pragma unroll
           for (int i = 0; i < XI; ++i) {
             const int k = tid + i * DF_THREADS;
-            pv[j][i] = k < d ? pr[pp * xpstride + k] : 0.f;
+            pv[j][i] = pr[pp * xpstride + (k < d ? k : d - 1)];
           }
         }
 #pragma unroll
@@ -1055,7 +1062,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
         const int k = tid + i * DF_THREADS;
-        xe[i] = (sp[i] + xb[i]) + xe[i];
+        xe[i] = k < d ? (sp[i] + (xbias ? xb[i] : 0.f)) + xe[i] : 0.f;
         if (h == 0 && k < d) xout[(int64_t)b * d + k] = xe[i];
       }
     }
