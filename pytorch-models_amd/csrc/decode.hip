@@ -238,9 +238,29 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
       }
     }
+    // gamma / beta of this lane's K positions: in REGISTERS for the small instantiations (requested behind x like any operand:
+    // one round trip for everything).  Staged through LDS by a `gb[k] = gamma[k]` loop - still the form of the large ones,
+    // which have no registers for it - hipcc waits vmcnt(0) in front of every LDS write: x and a round trip per loop trip
+    // BEFORE the weights are even requested (ISA of the fc1 launch: 2 loads, wait, ds_write, 2 loads, wait, ...)
+    constexpr bool GREG = LN && NSTEP <= 4;
+    f32x4 gv[GREG ? NSTEP : 1][2], bv[GREG ? NSTEP : 1][2];
+    if constexpr (GREG) {
+#pragma unroll
+      for (int u = 0; u < NSTEP; ++u) {
+        int s = sb + 4 * u;
+        s = s < ks1 ? s : ks1 - 1;
+        const int k0 = s * 32 + kq * 8;
+        gv[u][0] = *(const f32x4*)(gamma + k0);
+        gv[u][1] = *(const f32x4*)(gamma + k0 + 4);
+        bv[u][0] = *(const f32x4*)(beta + k0);
+        bv[u][1] = *(const f32x4*)(beta + k0 + 4);
+      }
+    }
     if constexpr (LN) {
       __builtin_amdgcn_sched_barrier(0);
-      for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
+      if constexpr (!GREG) {
+        for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < NSTEP; ++u) {
@@ -324,7 +344,10 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i] = xv[u][t][0][i]; v[4 + i] = xv[u][t][1][i]; }
-        if constexpr (LN) {
+        if constexpr (GREG) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gv[u][i >> 2][i & 3] + bv[u][i >> 2][i & 3];
+        } else if constexpr (LN) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gb[k0 + i] + gb[GBK + k0 + i];
         }
@@ -498,9 +521,8 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
                                                          const float* __restrict__ bias, int M, int N, int K,
                                                          float* __restrict__ ws_val, int* __restrict__ ws_idx, int ntiles,
                                                          int halves) {
-  constexpr int NSTEP = 16 / NW, GBK = 512;  // K <= 512: at most 16 K steps of 32
+  constexpr int NSTEP = 16 / NW;  // K <= 512: at most 16 K steps of 32
   __shared__ float part[NW * 64];
-  __shared__ float gb[2 * GBK];
   __shared__ __attribute__((aligned(16))) float red[2][NW * NF * MT * 64 * 4];
   __shared__ float tbv[2][NF][MT * 16];  // NW == 8: per step and feature tile, the rows' (max, index)
   __shared__ int tbi[2][NF][MT * 16];
@@ -523,6 +545,19 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
       xv[u][t][0] = *(const f32x4*)xr;
       xv[u][t][1] = *(const f32x4*)(xr + 4);
     }
+  }
+  // gamma / beta of this lane's K positions, in registers (see dec_linear_kernel: the LDS staging loop made hipcc wait for
+  // everything in flight - here the first weight rows, from HBM - in front of the LayerNorm)
+  f32x4 gv[NSTEP][2], bv[NSTEP][2];
+#pragma unroll
+  for (int u = 0; u < NSTEP; ++u) {
+    int s = wave + NW * u;
+    s = s < ksteps ? s : ksteps - 1;
+    const int k0 = s * 32 + kq * 8;
+    gv[u][0] = *(const f32x4*)(gamma + k0);
+    gv[u][1] = *(const f32x4*)(gamma + k0 + 4);
+    bv[u][0] = *(const f32x4*)(beta + k0);
+    bv[u][1] = *(const f32x4*)(beta + k0 + 4);
   }
   // ---- vocabulary tiles: inner step q = (tile, half): 32 weight rows.  The first step's rows are requested HERE, right behind x
   // (loads return in order: x first) and in front of the LayerNorm, whose barriers no load crosses: requested behind it
@@ -548,7 +583,6 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
       }
     }
   }
-  for (int k = tid; k < K; k += 64 * NW) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
   auto part_sum = [&](int r) {  // over the waves, pairwise (NW = 4: the order of the 4-wave kernels)
     float h0 = (part[r] + part[64 + r]) + (part[128 + r] + part[192 + r]);
     if constexpr (NW == 8) h0 += (part[256 + r] + part[320 + r]) + (part[384 + r] + part[448 + r]);
@@ -610,7 +644,7 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
 #pragma unroll
       for (int i = 0; i < 4; ++i) { v[i] = xv[u][t][0][i]; v[4 + i] = xv[u][t][1][i]; }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gb[k0 + i] + gb[GBK + k0 + i];
+      for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean[t]) * rstd[t] * gv[u][i >> 2][i & 3] + bv[u][i >> 2][i & 3];
       split3(v, xh[u][t], xm[u][t], xl[u][t]);
     }
   }
