@@ -1354,11 +1354,25 @@ __global__ __launch_bounds__(256) void dec_argmax_reduce_kernel(const float* __r
   }
   float bv = -INFINITY, second = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = tid; i < nwg; i += 256) {
-    const float v = ws_val[(int64_t)b * nwg + i];
-    const int ix = ws_idx[(int64_t)b * nwg + i];
-    if (v > bv || (v == bv && ix < bi)) { second = fmaxf(second, bv); bv = v; bi = ix; }
-    else second = fmaxf(second, v);
+  // four (value, index) pairs per thread requested together, branch-free (clamped index, the repeats dropped below): one
+  // request per loop trip made every trip a dependent memory round trip (811 tiles = 4 trips per thread at Whisper's vocabulary)
+  for (int i0 = tid; i0 < nwg; i0 += 4 * 256) {
+    float v4[4];
+    int x4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + 256 * j;
+      const int ic = i < nwg ? i : nwg - 1;
+      v4[j] = ws_val[(int64_t)b * nwg + ic];
+      x4[j] = ws_idx[(int64_t)b * nwg + ic];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = i0 + 256 * j < nwg ? v4[j] : -INFINITY;
+      const int ix = i0 + 256 * j < nwg ? x4[j] : 0x7fffffff;
+      if (v > bv || (v == bv && ix < bi)) { second = fmaxf(second, bv); bv = v; bi = ix; }
+      else second = fmaxf(second, v);
+    }
   }
   // (winner, runner-up) over the wave: partners 1, 2 lanes away by quad permutes, 4 by the half row's mirror (the quads are
   // uniform by then), 8 by a row rotate, 16 / 32 by v_permlane16 / 32_swap - no LDS round trips (see dpp_mov)
