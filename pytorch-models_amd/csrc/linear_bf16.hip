@@ -722,9 +722,31 @@ __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __r
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int p = 0; p < np; ++p) {  // fixed order: deterministic
-    s1 += part[(m * np + p) * 2];
-    s2 += part[(m * np + p) * 2 + 1];
+  if ((np & 1) == 0) {
+    // sixteen pairs per trip requested together (branch-free: clamped index, repeats dropped), added in pair order - the
+    // one-pair-per-trip loop below compiles to load, vmcnt(0), add, branch: np dependent round trips, the whole 4.3 us
+    const float* pr = part + m * np * 2;
+    for (int p0 = 0; p0 < np; p0 += 16) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int p = p0 + 2 * j;
+        v[j] = *(const f32x4*)(pr + (p < np ? p : np - 2) * 2);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = p0 + 2 * j < np;
+        s1 += ok ? v[j][0] : 0.f;
+        s2 += ok ? v[j][1] : 0.f;
+        s1 += ok ? v[j][2] : 0.f;
+        s2 += ok ? v[j][3] : 0.f;
+      }
+    }
+  } else {
+    for (int p = 0; p < np; ++p) {  // fixed order: deterministic
+      s1 += part[(m * np + p) * 2];
+      s2 += part[(m * np + p) * 2 + 1];
+    }
   }
   const float mean = s1 * inv_n;
   const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
