@@ -635,9 +635,6 @@ __global__ __launch_bounds__(64 * NW) void dec_logits_kernel(const float* __rest
   bf16x8 xh[NSTEP][MT], xm[NSTEP][MT], xl[NSTEP][MT];
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
-    int s = wave + NW * u;
-    s = s < ksteps ? s : ksteps - 1;
-    const int k0 = s * 32 + kq * 8;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       float v[8];
