@@ -257,9 +257,19 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
       }
     }
     if constexpr (LN) {
+      // large instantiations: gamma / beta through registers into LDS - every request of the trip leaves before the first LDS
+      // write (the staging loop `gb[k] = gamma[k]` waited vmcnt(0) per trip: K / 256 dependent round trips in front of the weights)
+      constexpr int GN = GREG ? 1 : (GBK + 255) / 256;
+      float gr[GN], br[GN];
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!GREG) {
-        for (int k = tid; k < K; k += 256) { gb[k] = gamma[k]; gb[GBK + k] = beta[k]; }
+#pragma unroll
+        for (int j = 0; j < GN; ++j) {
+          const int k = tid + 256 * j;
+          const int kc = k < K ? k : K - 1;
+          gr[j] = gamma[kc];
+          br[j] = beta[kc];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -268,6 +278,14 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(const float* __restrict
         s = s < ks1 ? s : ks1 - 1;
 #pragma unroll
         for (int f = 0; f < FT; ++f) a[u][f] = *(const bf16x8*)(wp[f] + s * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!GREG) {
+#pragma unroll
+        for (int j = 0; j < GN; ++j) {
+          const int k = tid + 256 * j;
+          if (k < K) { gb[k] = gr[j]; gb[GBK + k] = br[j]; }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     } else {
