@@ -982,12 +982,12 @@ template <> struct KV8<float> { typedef f32x8 type; };
 // round trips cost the block 5-6 us, as much as the launch they replaced.
 template <bool SELF, int NCH, typename KT, bool CHAIN>
 __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
-    const float* __restrict__ x, int d, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    const bf16* __restrict__ Wp, const float* __restrict__ bp,  // SELF: packed [q|k|v] (3*inner, d); cross: q (inner, d)
+    const float* x, int d, const float* gamma, const float* beta, float eps,
+    const bf16* Wp, const float* bp,  // SELF: packed [q|k|v] (3*inner, d); cross: q (inner, d)
     KT* Kc, KT* Vc, int64_t sb, int64_t sh, int64_t sk, const int* __restrict__ pos_ptr, int lk_const,
     float* __restrict__ out, int H,
     // CHAIN only:
-    const float* __restrict__ xparts, int np, int64_t xpstride, int64_t xprow, const float* __restrict__ xbias,
+    const float* xparts, int np, int64_t xpstride, int64_t xprow, const float* xbias,
     float* __restrict__ xout, const bf16* __restrict__ Wo, float* __restrict__ hparts) {
   typedef typename KV8<KT>::type kv8;
   __shared__ float sc[DA_MAXK];
@@ -1006,11 +1006,17 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   // load issued where it is used exposes one L2 latency each (measured: the block spent ~2 us of its 10-25 us waiting on them)
   PM_STAMP(0);
   const float* xr = x + (int64_t)b * d;
-  float xe[3], ge[3], be[3];
+  // The block's first requests are BRANCH-FREE (clamped indices, values dropped by selects) and their sources carry NO
+  // __restrict__: one basic block, so hipcc's waits in front of the LayerNorm are exact counts (with a block per `cond ? load :
+  // 0` it waited vmcnt(12): half the projection weights requested BEHIND the row), and loads that may alias the kernel's stores
+  // keep their place relative to a sched_barrier - read-only __restrict__ loads float past it when the DAG is linearised, and the
+  // parts ended up behind the 128 KB of weights and keys.
+  constexpr int XR = (NCH * 64 + DF_THREADS - 1) / DF_THREADS;  // row elements per thread of this instantiation
+  float xe[XR], ge[XR], be[XR];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < XR; ++i) {
     const int k = tid + i * DF_THREADS;
-    xe[i] = k < d ? xr[k] : 0.f;
+    xe[i] = xr[k < d ? k : d - 1];
   }
   // CHAIN, IN side: the first eight parts and the bias are REQUESTED here, behind the row, and added only after the projection
   // weights and the first K passes have been requested too (below): consumed here they held every later request back by one
@@ -1037,15 +1043,19 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       }
     }
   }
+  __builtin_amdgcn_sched_barrier(0);  // the row and its parts first: what the LayerNorm waits for
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < XR; ++i) {
     const int k = tid + i * DF_THREADS;
-    ge[i] = k < d ? gamma[k] : 0.f;
-    be[i] = k < d ? beta[k] : 0.f;
+    ge[i] = gamma[k < d ? k : d - 1];
+    be[i] = beta[k < d ? k : d - 1];
   }
   float bpe[SELF ? 3 : 1];
 #pragma unroll
-  for (int o = 0; o < (SELF ? 3 : 1); ++o) bpe[o] = bp ? bp[o * inner + h * 64 + (tid >> 3)] : 0.f;
+  for (int o = 0; o < (SELF ? 3 : 1); ++o) {
+    const float bvl = (bp ? bp : gamma)[bp ? o * inner + h * 64 + (tid >> 3) : 0];
+    bpe[o] = bp ? bvl : 0.f;
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- projection weights: 8 lanes per output row, lane p owns 16-byte chunks p, p+8, ...
@@ -1061,7 +1071,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       const bf16* wr = Wp + ((int64_t)o * inner + h * 64 + prow) * d + pl * 8;
 #pragma unroll
       for (int i = 0; i < NCH; ++i)
-        if (i < nch) wv[o][i] = *(const bf16x8*)(wr + i * 64);
+        wv[o][i] = *(const bf16x8*)(wr + (i < nch ? i : nch - 1) * 64);  // (chunks past d: a repeat, multiplied by zeros below)
     }
   }
   // ---- the K stream does not depend on q: request its first NKU passes now - AFTER the projection weights, so the
@@ -1111,7 +1121,7 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
         const int k = tid + i * DF_THREADS;
-        xe[i] = k < d ? (sp[i] + (xbias ? xb[i] : 0.f)) + xe[i] : 0.f;
+        xe[i] = (sp[i] + (xbias ? xb[i] : 0.f)) + xe[i];
         if (h == 0 && k < d) xout[(int64_t)b * d + k] = xe[i];
       }
     }
@@ -1120,19 +1130,20 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
   // ---- LayerNorm of row b (two-pass from registers)
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) s += xe[i];
+  for (int i = 0; i < XR; ++i) s += tid + i * DF_THREADS < d ? xe[i] : 0.f;
   const float mean = block_reduce8(s, scratch, false) / (float)d;
   float q2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < XR; ++i) {
     const int k = tid + i * DF_THREADS;
-    if (k < d) q2 = fmaf(xe[i] - mean, xe[i] - mean, q2);
+    const float dv = k < d ? xe[i] - mean : 0.f;
+    q2 = fmaf(dv, dv, q2);
   }
   const float rstd = rsqrtf(block_reduce8(q2, scratch + DF_WAVES, false) / (float)d + eps);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < XR; ++i) {  // (zeros from d up to the instantiation's width: the projection runs all NCH chunks)
     const int k = tid + i * DF_THREADS;
-    if (k < d) xn[k] = (xe[i] - mean) * rstd * ge[i] + be[i];
+    if (k < NCH * 64) xn[k] = k < d ? (xe[i] - mean) * rstd * ge[i] + be[i] : 0.f;
   }
   __syncthreads();
   PM_STAMP(2);
@@ -1144,15 +1155,14 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
       const bf16* wr = Wp + ((int64_t)o * inner + h * 64 + prow) * d + pl * 8;
 #pragma unroll
       for (int i = 0; i < NCH; ++i)
-        if (i < nch) wv[0][i] = *(const bf16x8*)(wr + i * 64);
+        wv[0][i] = *(const bf16x8*)(wr + (i < nch ? i : nch - 1) * 64);
     }
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      if (i < nch) {
-        const float* xp = xn + i * 64 + pl * 8;
+    for (int i = 0; i < NCH; ++i) {
+      const float* xp = xn + i * 64 + pl * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[UPFRONT ? o : 0][i][e], xp[e], acc);
-      }
+      for (int e = 0; e < 8; ++e) acc = fmaf((float)wv[UPFRONT ? o : 0][i][e], xp[e], acc);
+    }
     acc = sum8_dpp(acc);
     if (pl == 0) {
       float v = acc + bpe[o];
