@@ -1211,7 +1211,12 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     sv = sum8_dpp(sv);                                                                                                 \
     const int key_ = (k0_) + u * 64 + wave * 8 + ks;                                                                   \
     if (c == 0 && key_ < Lc) sc[key_] = sv * 0.125f;                                                                   \
+    lmax = fmaxf(lmax, key_ < Lc ? sv * 0.125f : -INFINITY);                                                           \
   }
+  // the scores' maximum rides along with the scores (a lane's running maximum, the wave's by DPP / permlane at the end, the 8
+  // waves' through scratch behind the barrier that publishes the scores anyway): the separate pass over the score array and
+  // its block reduction - one workgroup barrier and two LDS round trips of the block's critical path - are gone
+  float lmax = -INFINITY;
   if constexpr (!SELF && PM_CROSS_DB) {
     kv8 kw[NKU];
     for (int k0 = 0; k0 < Lc;) {
@@ -1237,6 +1242,11 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     for (int i = 0; i < 4; ++i) sv = fmaf(q1[i], qkv[64 + c * 8 + 4 + i], sv);
     sv = sum8_dpp(sv);
     if (c == 0) sc[Lk - 1] = sv * 0.125f;
+    lmax = fmaxf(lmax, sv * 0.125f);
+  }
+  {
+    const float wmax = dwave_max(lmax);
+    if (lane == 0) scratch[2 * DF_WAVES + wave] = wmax;
   }
   PM_STAMP(4);
   // V does not depend on the scores: request the first NKU passes now, so they fly during the softmax reductions
@@ -1248,9 +1258,9 @@ __global__ __launch_bounds__(DF_THREADS) void dec_attn_fused_kernel(
     vv[u] = SELF ? *(const kv8*)(vb + key * sk) : __builtin_nontemporal_load((const kv8*)(vb + key * sk));
   }
   __syncthreads();
-  float mx = -INFINITY;
-  for (int k = tid; k < Lk; k += DF_THREADS) mx = fmaxf(mx, sc[k]);
-  mx = block_reduce8(mx, scratch + 2 * DF_WAVES, true);
+  float mx = scratch[2 * DF_WAVES];
+#pragma unroll
+  for (int w = 1; w < DF_WAVES; ++w) mx = fmaxf(mx, scratch[2 * DF_WAVES + w]);
   float sum = 0.f;
   for (int k = tid; k < Lk; k += DF_THREADS) {
     const float p = expf(sc[k] - mx);
