@@ -726,15 +726,17 @@ __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __r
     // sixteen pairs per trip requested together (branch-free: clamped index, repeats dropped), added in pair order - the
     // one-pair-per-trip loop below compiles to load, vmcnt(0), add, branch: np dependent round trips, the whole 4.3 us
     const float* pr = part + m * np * 2;
-    for (int p0 = 0; p0 < np; p0 += 16) {
-      f32x4 v[8];
+    // two 16-byte requests per trip: within 16 registers this kernel fits on a SIMD beside the other stream's persistent GEMM
+    // (2 waves x 240 of 512 registers) instead of waiting for that GEMM's workgroups to leave (PM_FINALIZE_WIDE=1: 8 per trip)
+    for (int p0 = 0; p0 < np; p0 += 4) {
+      f32x4 v[2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const int p = p0 + 2 * j;
         v[j] = *(const f32x4*)(pr + (p < np ? p : np - 2) * 2);
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const bool ok = p0 + 2 * j < np;
         s1 += ok ? v[j][0] : 0.f;
         s2 += ok ? v[j][1] : 0.f;

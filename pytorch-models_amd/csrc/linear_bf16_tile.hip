@@ -314,18 +314,30 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 #pragma unroll
       for (int q = 0; q < RPF; ++q) PM_TLOAD_RESID(q, q, m0, n0, efr, efq);
     }
+    // bias (and the LayerNorm fold's column sums) of a 64-feature half: the first half's at the start, the second half's
+    // requested in front of the first half's LAST block - the finished blocks' accumulators are dead by then (see the end of the
+    // epilogue) - instead of at the top of the second half, where they were waited for with the whole workgroup idle
+    f32x4 bvec[4], svec[LNC ? 4 : 1], bnxt[4], snxt[LNC ? 4 : 1];
+#define PM_TLOAD_BIAS(bd_, sd_, hf_)                                                                                  \
+  _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                   \
+    int n = n0 + (hf_) * 64 + jj * 16 + efq * 4;                                                                       \
+    n = n < N ? n : N - 4; /* features beyond N are never stored */                                                    \
+    bd_[jj] = bias ? *(const f32x4*)((const char*)bias + (uint32_t)n * 4) : f32x4{0.f, 0.f, 0.f, 0.f};                 \
+    if constexpr (LNC) sd_[jj] = *(const f32x4*)((const char*)ln.s + (uint32_t)n * 4);                                 \
+  }
+    PM_TLOAD_BIAS(bvec, svec, 0);
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {  // 64-feature halves of the wave's 128 features
-      f32x4 bvec[4], svec[LNC ? 4 : 1];
+      if (hf == 1) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        int n = n0 + hf * 64 + jj * 16 + efq * 4;
-        n = n < N ? n : N - 4;  // features beyond N are never stored
-        bvec[jj] = bias ? *(const f32x4*)((const char*)bias + (uint32_t)n * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (LNC) svec[jj] = *(const f32x4*)((const char*)ln.s + (uint32_t)n * 4);
+        for (int jj = 0; jj < 4; ++jj) {
+          bvec[jj] = bnxt[jj];
+          if constexpr (LNC) svec[jj] = snxt[jj];
+        }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        if (hf == 0 && i == MI - 1) PM_TLOAD_BIAS(bnxt, snxt, 1);
         const int q = hf * MI + i;
         if constexpr (RES) {
           if (q + RPF < 2 * MI) PM_TLOAD_RESID(q + RPF, (q + RPF) % (RPF + 1), m0, n0, efr, efq);
@@ -383,9 +395,19 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
         }
       }
     }
+#ifndef PM_TILE_NO_ACC_KILL
+    // The accumulators END here: the next tile's first MFMAs start from zero, but in the flat loop hipcc cannot see that and keeps
+    // all 32 MI accumulator registers live through the whole epilogue.  An empty asm that DEFINES them closes their live ranges at
+    // each block's last use - the epilogue's own temporaries then fit where the finished blocks' accumulators were.
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) asm volatile("" : "=v"(acc[j][i]));
+#endif
   }
 #undef PM_TSTAGE_NEXT
 #undef PM_TLOAD_RESID
+#undef PM_TLOAD_BIAS
 }
 
 }  // namespace
