@@ -33,6 +33,10 @@ for k in auto 6 7 2; do
   if [ $k == auto ]; then python3 tools/tile_check.py --time-only; else PM_GEMM_KERNEL=$k python3 tools/tile_check.py --time-only; fi
 done > $out/gemm_kernels_steady_state.txt 2>&1
 python3 tools/blas_reference_bench.py > $out/vendor_blas_steady_state.txt 2>&1
+echo "whisper step traffic (eager decode: counter collection cannot sample graph replays)"
+timeout -k 5 250 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $out/st_raw_f -- python3 bench.py --workload whisper --no-graph --steps 1 --warmup 0 --no-cpu-baseline --no-exact > $out/st_f.log 2>&1 || echo "step fetch pass failed"
+timeout -k 5 250 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/st_w -- python3 bench.py --workload whisper --no-graph --steps 1 --warmup 0 --no-cpu-baseline --no-exact > $out/st_w.log 2>&1 || echo "step write pass failed"
+python3 tools/collect_step_traffic.py $out/st_raw_f $out/st_w $out/whisper_step_traffic.json > /dev/null || echo "step traffic failed"
 echo "bench line"
 python3 bench.py --steps 20 --warmup 5 > $out/bench_line_default_run.json 2> $out/bench_line.err
 python3 tools/exact_time.py > $out/exact_mode_cost.txt 2>&1
