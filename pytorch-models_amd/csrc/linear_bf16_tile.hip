@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
       }
     }
     const char* xcur = smem + buf * STAGE;
-    const char* wcur = xcur + BM * 128;
+    [[maybe_unused]] const char* wcur = xcur + BM * 128;  // (the asm-read form addresses the weight rows off xcur)
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       bf16x8 a[8], b[MI];
