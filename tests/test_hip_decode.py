@@ -239,6 +239,20 @@ def test_greedy_ids_bit_exact_vs_oracle(tag, seed):
     assert torch.equal(greedy_decode(w.decoder, memory, prompt.cuda(), n_new, fused=False), toks)
 
 
+@pytest.mark.parametrize("tag,seed", [("tiny", 55), ("base", 56)])
+def test_greedy_ids_without_the_chain_of_deferred_sums(tag, seed, monkeypatch):
+    """PM_DEC_CHAIN=0 (every projection its own launch with its own combining pass: round 2's launch list, 50 launches per
+    step instead of 42) decodes the oracle's ids too, and the same ids as the chained default."""
+    w, sd, memory, prompt, _ = _setup(tag, seed, 2)
+    n_new = 32
+    chained = w.decoder.generate(memory, prompt.cuda(), n_new)
+    monkeypatch.setenv("PM_DEC_CHAIN", "0")
+    plain = w.decoder.generate(memory, prompt.cuda(), n_new)
+    want, margins = RW.greedy_cached(sd, "decoder.", prompt, memory.float().cpu(), n_new, rp=kv_round)
+    assert _compare(plain, want, margins, 4) == 0
+    assert torch.equal(plain, chained)
+
+
 def test_greedy_end_to_end_agrees_with_reference_golden(golden):
     """Full pipeline (HIP log-mel + bf16 encoder + decoder) against the reference's fp32 golden ids.  The bf16
     encoder perturbs the memory by ~1e-2, so ids may legitimately diverge at small margins; report the agreement
