@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void attn_fwd_hd64(const bf16* __restrict__ Q,
 
   // this lane's query row (clamped for loads; masked at the store)
   const int qi = q0 + wave * 32 + r;
-  const int qi_ld = qi < Lq ? qi : Lq - 1;
+  [[maybe_unused]] const int qi_ld = qi < Lq ? qi : Lq - 1;
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(Qp + (int64_t)qi_ld * qst + s * 16 + hh * 8);
@@ -275,6 +275,73 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_dst
                : "memory");
 }
 
+// In-kernel stamps (variant builds only: -DPM_AH_STAMPS=1; tools/attn_stamps.py): per workgroup and wave, its PM_AH_STAMP_IT-th head.
+#ifndef PM_AH_STAMPS
+#define PM_AH_STAMPS 0
+#endif
+#ifndef PM_AH_TRIM
+#define PM_AH_TRIM 1
+#endif
+#ifndef PM_AH_SOLO
+#define PM_AH_SOLO 1
+#endif
+#ifndef PM_AH_SOLO4
+#define PM_AH_SOLO4 1
+#endif
+#ifndef PM_AH_LATE
+#define PM_AH_LATE 1
+#endif
+#ifndef PM_AH_KPF
+#define PM_AH_KPF 1
+#endif
+#ifndef PM_AH_QLDS
+#define PM_AH_QLDS 0
+#endif
+#ifndef PM_AH_STAMP_IT
+#define PM_AH_STAMP_IT 5
+#endif
+#if PM_AH_STAMPS
+__device__ unsigned long long g_ah_stamps[256 * 8 * 8];
+#define PM_AH_STAMP(i_)                                                                                              \
+  do {                                                                                                               \
+    if (it == PM_AH_STAMP_IT && lane == 0 && blockIdx.x < 256) g_ah_stamps[(blockIdx.x * 8 + wave) * 8 + (i_)] = wall_clock64(); \
+  } while (0)
+#else
+#define PM_AH_STAMP(i_)
+#endif
+
+// the same with the address as uniform 64-bit base (SGPR pair) + 32-bit lane offset: no 64-bit vector arithmetic per request
+__device__ __forceinline__ void glds16_hidden_s(const void* uniform_base, unsigned lane_off, unsigned lds_dst_wave_base) {
+  unsigned keep;
+  const uint64_t b = (uint64_t)(uintptr_t)uniform_base;
+  // (readfirstlane returns int: without the unsigned casts the low word would be sign-extended over the high one)
+  const uint64_t sb = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32) |
+                      (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_off), "s"(sb), "s"(dst)
+               : "memory");
+}
+
+// four pieces behind ONE write of M0: the instruction's immediate offset moves the LDS address and the global address alike
+// (piece i of the group: + 1024 i), so lane offset i is passed less 1024 i (callers: off[i] >= 1024 i)
+__device__ __forceinline__ void glds16_hidden_s4(const void* uniform_base, unsigned o0, unsigned o1, unsigned o2, unsigned o3,
+                                                 unsigned lds_dst_wave_base) {
+  unsigned keep;
+  const uint64_t b = (uint64_t)(uintptr_t)uniform_base;
+  const uint64_t sb = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32) |
+                      (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %5\n\tglobal_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+      "global_load_lds_dwordx4 %3, %5 offset:2048\n\tglobal_load_lds_dwordx4 %4, %5 offset:3072\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(o0), "v"(o1 - 1024u), "v"(o2 - 2048u), "v"(o3 - 3072u), "s"(sb), "s"(dst)
+      : "memory");
+}
+
 template <int NB>
 __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q, int64_t qsb, int64_t qst,
                                                       const bf16* __restrict__ K, int64_t ksb, int64_t kst,
@@ -287,7 +354,7 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int qi = wave * 32 + r;
-  const int qi_ld = qi < Lq ? qi : Lq - 1;
+  [[maybe_unused]] const int qi_ld = qi < Lq ? qi : Lq - 1;
   const bool live = wave * 32 < Lq;
   const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
   const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
@@ -296,22 +363,58 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
 
   // K / V rows of one head straight into LDS: NB pieces (8 rows of 128 bytes) per wave, the swizzles ride on the SOURCE
   // chunk; rows past Lk repeat row Lk - 1 (finite values under probabilities that are exactly 0)
-#define PM_AH_ISSUE(HEAD, BUFI)                                                                                  \
+#define PM_AH_PIECE(HEAD, BUFI, PI_)                                                                             \
   {                                                                                                              \
     const int b_ = (HEAD) / H, h_ = (HEAD) - b_ * H;                                                             \
     const bf16* Kp_ = K + (int64_t)b_ * ksb + h_ * 64;                                                           \
     const bf16* Vp_ = V + (int64_t)b_ * vsb + h_ * 64;                                                           \
     const unsigned base_ = lds0 + (BUFI) * BUF;                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                             \
-      const int pi = wave + 8 * i;                                                                               \
-      const bool isv = pi >= 4 * NB;                                                                             \
-      const int piece = isv ? pi - 4 * NB : pi;                                                                  \
-      const int row = piece * 8 + (lane >> 3), pos = lane & 7;                                                   \
-      const int src = row < Lk ? row : Lk - 1;                                                                   \
-      const bf16* g_ = !isv ? Kp_ + (int64_t)src * kst + swz_pos(row, pos) * 8                                     \
-                            : Vp_ + (int64_t)src * vst + (pos ^ (((row >> 1) & 1) << 2)) * 8;                     \
+    const int pi = (PI_);                                                                                        \
+    const bool isv = pi >= 4 * NB;                                                                               \
+    const int piece = isv ? pi - 4 * NB : pi;                                                                    \
+    const int row = piece * 8 + (lane >> 3), pos = lane & 7;                                                     \
+    const int src = row < Lk ? row : Lk - 1;                                                                     \
+    const bf16* g_ = !isv ? Kp_ + (int64_t)src * kst + swz_pos(row, pos) * 8                                       \
+                          : Vp_ + (int64_t)src * vst + (pos ^ (((row >> 1) & 1) << 2)) * 8;                       \
+    /* pieces wholly past the keys stay unrequested (PM_AH_TRIM): their K rows only meet scores that are overwritten with \
+       -1e30, their V rows (16-key steps past Lk) are never read; whatever the image holds there, NaN patterns included */ \
+    if (!PM_AH_TRIM || piece * 8 < (isv ? ((Lk + 15) & ~15) : Lk))                                               \
       glds16_hidden(g_, base_ + (isv ? IMG : 0) + piece * 1024);                                                 \
-    }                                                                                                            \
+  }
+#define PM_AH_ISSUE(HEAD, BUFI)                                                                                  \
+  {                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) PM_AH_PIECE(HEAD, BUFI, wave + 8 * i)                         \
+  }
+  // PM_AH_SOLO: with Lq <= 224 (ViT's 197) wave 7 owns no queries and requests EVERY piece of the next head - an LDS-DMA
+  // request costs the wave that issues it ~200 cycles in which it issues nothing else (the stamps of tools/attn_stamps.py:
+  // the 15 requests per wave behind the barrier held every wave 1.4-2.8 us of a 6.7 us head; with the pieces gone the
+  // queries and stores take 0.16 us).  Uniform base + 32-bit lane offset keeps wave 7's own arithmetic per piece at 4 ops.
+#define PM_AH_ISSUE_SOLO(HEAD, BUFI)                                                                             \
+  {                                                                                                              \
+    const int b_ = (HEAD) / H, h_ = (HEAD) - b_ * H;                                                             \
+    const bf16* Kp_ = K + (int64_t)b_ * ksb + h_ * 64;                                                           \
+    const bf16* Vp_ = V + (int64_t)b_ * vsb + h_ * 64;                                                           \
+    const unsigned base_ = lds0 + (BUFI) * BUF;                                                                  \
+    const int lrow = lane >> 3, pos = lane & 7;                                                                  \
+    const unsigned kso = (unsigned)swz_pos(lrow, pos) * 16, vso = (unsigned)(pos ^ (((lrow >> 1) & 1) << 2)) * 16; \
+    const int nk_ = PM_AH_TRIM ? (Lk + 7) >> 3 : 4 * NB, nv_ = PM_AH_TRIM ? ((Lk + 15) & ~15) >> 3 : 4 * NB;     \
+    const unsigned ks2 = (unsigned)(kst * 2), vs2 = (unsigned)(vst * 2);                                         \
+    int p_ = 0;                                                                                                  \
+    /* swz_pos(row, pos) with row = 8 p_ + lrow: the piece's parity flips chunk bit 2 */                         \
+    for (; PM_AH_SOLO4 && p_ + 4 <= nk_; p_ += 4)                                                                \
+      glds16_hidden_s4(Kp_, (unsigned)min(p_ * 8 + lrow, Lk - 1) * ks2 + kso,                                    \
+                       (unsigned)min(p_ * 8 + 8 + lrow, Lk - 1) * ks2 + (kso ^ 64u),                             \
+                       (unsigned)min(p_ * 8 + 16 + lrow, Lk - 1) * ks2 + kso,                                    \
+                       (unsigned)min(p_ * 8 + 24 + lrow, Lk - 1) * ks2 + (kso ^ 64u), base_ + p_ * 1024);        \
+    for (; p_ < nk_; ++p_)                                                                                       \
+      glds16_hidden_s(Kp_, (unsigned)min(p_ * 8 + lrow, Lk - 1) * ks2 + (kso ^ ((unsigned)(p_ & 1) << 6)), base_ + p_ * 1024); \
+    for (p_ = 0; PM_AH_SOLO4 && p_ + 4 <= nv_; p_ += 4)                                                          \
+      glds16_hidden_s4(Vp_, (unsigned)min(p_ * 8 + lrow, Lk - 1) * vs2 + vso,                                    \
+                       (unsigned)min(p_ * 8 + 8 + lrow, Lk - 1) * vs2 + vso,                                     \
+                       (unsigned)min(p_ * 8 + 16 + lrow, Lk - 1) * vs2 + vso,                                    \
+                       (unsigned)min(p_ * 8 + 24 + lrow, Lk - 1) * vs2 + vso, base_ + IMG + p_ * 1024);          \
+    for (; p_ < nv_; ++p_)                                                                                       \
+      glds16_hidden_s(Vp_, (unsigned)min(p_ * 8 + lrow, Lk - 1) * vs2 + vso, base_ + IMG + p_ * 1024);           \
   }
 #define PM_AH_LOADQ(HEAD, DST)                                                                                   \
   {                                                                                                              \
@@ -320,42 +423,140 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
     _Pragma("unroll") for (int s = 0; s < 4; ++s) DST[s] = *(const bf16x8*)(Qp_ + s * 16);                       \
   }
 
-#define PM_AH_STORE(HEAD)                                                                                        \
+#define PM_AH_STORE(HEAD) /* the four read-backs first (one LDS round trip), then the four stores */             \
   {                                                                                                              \
     const int b_ = (HEAD) / H, h_ = (HEAD) - b_ * H;                                                             \
-    bf16* op_ = O + (int64_t)b_ * osb + h_ * 64 + (lane & 7) * 8;                                                \
+    bf16* op_ = O + (int64_t)b_ * osb + h_ * 64 + (lane & 7) * 8 + (int64_t)(wave * 32 + (lane >> 3)) * ost;     \
+    bf16x8 o_[4];                                                                                                \
     _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) {                                                           \
       const int row = k4 * 8 + (lane >> 3);                                                                      \
-      const bf16x8 o = *(const bf16x8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) * 16));                      \
-      if (wave * 32 + row < Lq) *(bf16x8*)(op_ + (int64_t)(wave * 32 + row) * ost) = o;                          \
+      o_[k4] = *(const bf16x8*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) * 16));                              \
     }                                                                                                            \
+    _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4)                                                             \
+      if (wave * 32 + k4 * 8 + (lane >> 3) < Lq) *(bf16x8*)(op_ + (int64_t)(k4 * 8) * ost) = o_[k4];             \
+  }
+
+  // Queries.  PM_AH_QLDS 1: a wave's 32 query rows come in as four LDS-DMA pieces of 8 whole rows (full 128-byte lines, 8 per
+  // request) into its own 4 KiB staging area - which is free between the previous head's stores (right behind the barrier) and
+  // this head's transposition - and are read from there in the K fragment's layout when the head's arithmetic is done.  0: every
+  // lane loads its own row's 16-byte chunks (four requests of 32 partial lines each: 128 line accesses per wave and head against
+  // 56 for its K / V pieces and 32 for its stores - the stamps showed the CU's memory pipe, not HBM, holding the waves).
+#define PM_AH_QISSUE(HEAD)                                                                                       \
+  {                                                                                                              \
+    const int b_ = (HEAD) / H, h_ = (HEAD) - b_ * H;                                                             \
+    const bf16* Qp_ = Q + (int64_t)b_ * qsb + h_ * 64;                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+      const int row = j * 8 + (lane >> 3), pos = lane & 7;                                                       \
+      const int src = wave * 32 + row < Lq ? wave * 32 + row : Lq - 1;                                           \
+      glds16_hidden(Qp_ + (int64_t)src * qst + swz_pos(row, pos) * 8, lds0 + 2 * BUF + wave * 4096 + j * 1024);  \
+    }                                                                                                            \
+  }
+#define PM_AH_QREAD(DST)                                                                                         \
+  {                                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) DST[s] = *(const bf16x8*)(stg + r * 128 + swz_pos(r, 2 * s + hh) * 16); \
   }
 
   int head = blockIdx.x;
   if (head >= nheads) return;
-  bf16x8 qf[4], qn[4];
-  PM_AH_ISSUE(head, 0)
+  bf16x8 qf[4];
+  // a wave requests NB pieces per head, less at most one K and one V piece trimmed past the keys: with QW requests allowed
+  // in flight everything older than its pieces has landed
+  [[maybe_unused]] constexpr int QW = PM_AH_TRIM ? (NB > 2 ? NB - 2 : 0) : NB;
+  // (Lk >= 32: every clamped row offset of a group of four stays >= the 3 KiB the instruction offsets add)
+  const bool solo = PM_AH_SOLO && Lq <= 224 && Lk >= 32 && (int64_t)Lk * max(kst, vst) < (1ll << 30);
+#define PM_AH_KV(HEAD, BUFI)                                                                                     \
+  {                                                                                                              \
+    if (solo) {                                                                                                  \
+      if (wave == 7) PM_AH_ISSUE_SOLO(HEAD, BUFI)                                                                \
+    } else                                                                                                       \
+      PM_AH_ISSUE(HEAD, BUFI)                                                                                    \
+  }
+#if PM_AH_QLDS
+  if (live) PM_AH_QISSUE(head)
+  PM_AH_KV(head, 0)
+  if (live) {
+    if (solo) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a wave with queries has nothing else in flight
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QW) : "memory");  // in order: the queries are older than the K / V pieces
+    PM_AH_QREAD(qf)
+  }
+#else
+  bf16x8 qn[4];
+  PM_AH_KV(head, 0)
   PM_AH_LOADQ(head, qf)
 #pragma unroll
   for (int s = 0; s < 4; ++s) qn[s] = qf[s];
+#endif
   for (int it = 0; head < nheads; ++it, head += gridDim.x) {
     const int bufi = it & 1;
+    PM_AH_STAMP(0);
     // this wave's pieces of `head` (and its queries) have landed; everything else it has in flight is a head old
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PM_AH_STAMP(1);
     __builtin_amdgcn_s_barrier();  // ... everyone's have; and everyone is done with the other buffer
+    PM_AH_STAMP(2);
     const int nxt = head + gridDim.x;
-    if (nxt < nheads) {
-      PM_AH_ISSUE(nxt, bufi ^ 1)
-      PM_AH_LOADQ(nxt, qn)
-    }
-    // the PREVIOUS head's rows leave now, from the wave's staging area: their stores drain under this head's arithmetic
-    // instead of in front of the next wait
-    if (live && it > 0) PM_AH_STORE(head - (int)gridDim.x)
+    const bool more = nxt < nheads, prev = live && it > 0;
+    // The PREVIOUS head's rows leave from the wave's staging area (their stores drain under this head's arithmetic instead
+    // of in front of the next wait) and the next head's queries are requested: by waves 0-3 right here, by waves 4-7 - their
+    // partners on the SIMDs - behind their QK^T (PM_AH_LATE 1; 0 = all here).  A request costs its wave ~100 ns in which it
+    // issues nothing else, and with both partners in that phase the SIMD stood idle (stamps: waves 4-6 left it 2.0 us after
+    // the barrier, waves 0-3 1.2 us).
+#if PM_AH_QLDS
+#define PM_AH_SIDE()                                                                                             \
+  {                                                                                                              \
+    if (prev) PM_AH_STORE(head - (int)gridDim.x)                                                                 \
+    if (live && more) PM_AH_QISSUE(nxt) /* behind the stores' reads of the staging area */                       \
+  }
+#else
+#define PM_AH_SIDE()                                                                                             \
+  {                                                                                                              \
+    if (live && more) PM_AH_LOADQ(nxt, qn)                                                                       \
+    if (prev) PM_AH_STORE(head - (int)gridDim.x)                                                                 \
+  }
+#endif
+    const bool late = PM_AH_LATE && wave >= 4;
+    if (more) PM_AH_KV(nxt, bufi ^ 1)
+    if (!late) PM_AH_SIDE()
+    PM_AH_STAMP(3);
     if (live) {
       const char* kimg = smem + bufi * BUF;
       const char* vimg = kimg + IMG;
       // ---- S^T = K Q^T, all NB blocks
       f32x16 sc[NB];
+#if PM_AH_KPF
+      // The K fragments of blocks kb + 1 (and kb + 2's after block kb's MFMAs) are in flight while block kb's MFMAs run.  Left
+      // to hipcc the loop was  ds_read; s_waitcnt lgkmcnt(0); v_mfma  28 times over with ONE fragment register - the kernel
+      // sits at the register limit and its scheduler trades every read-ahead for pressure - i.e. an LDS round trip per MFMA
+      // (1.1 us for 0.37 us of matrix pipe).  So the reads are inline asm it does not track, and each block's MFMAs sit
+      // behind a counted wait that takes the fragments as operands (nothing that uses them can be scheduled above it).
+      // swz_pos(32 kb + r, c) does not depend on kb: four lane addresses, the block rides in the instruction offset.
+      bf16x8 kfr[2][4];
+      uint32_t ka[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ka[s] = (uint32_t)(uintptr_t)(PM_LDS const char*)kimg + (uint32_t)(r * 128 + swz_pos(r, 2 * s + hh) * 16);
+#define PM_AH_KREAD(KB_)                                                                                         \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                  \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kfr[(KB_) & 1][s]) : "v"(ka[s]), "n"((KB_) * 4096));
+#define PM_AH_KWAIT(N_, KB_)                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(%4)"                                                                           \
+               : "+v"(kfr[(KB_) & 1][0]), "+v"(kfr[(KB_) & 1][1]), "+v"(kfr[(KB_) & 1][2]), "+v"(kfr[(KB_) & 1][3])      \
+               : "n"(N_));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the counter starts from nothing of hipcc's own
+      PM_AH_KREAD(0)
+      if (NB > 1) PM_AH_KREAD(1)
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+        if (kb + 1 < NB) { PM_AH_KWAIT(4, kb) } else { PM_AH_KWAIT(0, kb) }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][s], qf[s], sc[kb], 0, 0, 0);
+        if (kb + 2 < NB) PM_AH_KREAD(kb + 2)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef PM_AH_KREAD
+#undef PM_AH_KWAIT
+#else
 #pragma unroll
       for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
@@ -367,6 +568,8 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
           sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc[kb], 0, 0, 0);
         }
       }
+#endif
+      if (late) PM_AH_SIDE()
       if (Lk < ROWS) {  // keys past Lk: last block only (the dispatcher picks the smallest NB that covers Lk)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -374,6 +577,7 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
           if (key >= Lk) sc[NB - 1][i] = -1e30f;
         }
       }
+      PM_AH_STAMP(4);
       // ---- exact softmax: max of the raw scores, the scale rides in the exponent's fma
       float mx = -1e30f;
 #pragma unroll
@@ -382,6 +586,7 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kb][i]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mc = mx * c;
+      PM_AH_STAMP(5);
       f32x2 ps2 = {0.f, 0.f};  // two chains for the row sum
       f32x16 oacc[2];
 #pragma unroll
@@ -422,6 +627,13 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
           }
         }
       }
+#if PM_AH_QLDS
+      if (more) {  // the next head's queries, requested a head's arithmetic ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next head's pieces, the previous head's stores, these queries
+        PM_AH_QREAD(qf)
+      }
+#endif
+      PM_AH_STAMP(6);
       const float ps = ps2[0] + ps2[1];
       const float inv = 1.0f / (ps + __shfl_xor(ps, 32, 64));
       // ---- O^T (query on the lane) -> row-major rows through the wave's own 4 KiB: chunk c of query row q at c ^ (q & 7)
@@ -434,17 +646,32 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
           for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * gq + j] * inv);
           *(bf16x4*)(stg + r * 128 + (((db * 4 + gq) ^ (r & 7)) * 16) + hh * 8) = o;
         }
+      PM_AH_STAMP(7);
     }
+#if !PM_AH_QLDS
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+#endif
   }
   if (live) PM_AH_STORE(head - (int)gridDim.x)  // the last head of this workgroup
 #undef PM_AH_STORE
+#undef PM_AH_PIECE
 #undef PM_AH_ISSUE
+#undef PM_AH_ISSUE_SOLO
+#undef PM_AH_KV
+#undef PM_AH_SIDE
 #undef PM_AH_LOADQ
+#undef PM_AH_QISSUE
+#undef PM_AH_QREAD
 }
 
 }  // namespace
+
+#if PM_AH_STAMPS
+extern "C" int pm_debug_ah_stamps(void* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ah_stamps), sizeof(unsigned long long) * 256 * 8 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 static int attention_impl(const void* q, int64_t q_stride_b, int64_t q_stride_t, const void* k, int64_t k_stride_b,
                           int64_t k_stride_t, const void* v, int64_t v_stride_b, int64_t v_stride_t, void* o,

@@ -26,6 +26,20 @@
 #include "common.h"
 
 namespace {
+// In-kernel stamps of the epilogue (variant builds only: -DPM_TILE_STAMPS=1; tools/tile_stamps.py): per workgroup, its first tile:
+// slot 0 = the last K step's barrier, 1 = epilogue start, 2 + q = behind block q, 15 = wave 0's view only.
+#ifndef PM_TILE_STAMPS
+#define PM_TILE_STAMPS 0
+#endif
+#if PM_TILE_STAMPS
+__device__ unsigned long long g_tile_stamps[256 * 16];
+#define PM_TSTAMP(i_, cond_)                                                                       \
+  do {                                                                                             \
+    if ((cond_) && threadIdx.x == 0) g_tile_stamps[blockIdx.x * 16 + (i_)] = wall_clock64();        \
+  } while (0)
+#else
+#define PM_TSTAMP(i_, cond_)
+#endif
 
 constexpr int TBN = 256, TBK = 64;
 #ifndef PM_TGROUP_M
@@ -177,6 +191,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 #define PM_TILE_ISSUE_SPLIT 1
 #endif
     if (!PM_TILE_ISSUE_SPLIT || wave < 4) PM_TSTAGE_NEXT();
+    PM_TSTAMP(0, ti == 0 && kt == nk - 1);
+    PM_TSTAMP(14, ti == 0 && kt == 0);
     if (kt == nk - 1) {
       // last K step of the tile: request what the epilogue needs first now, so that the latency hides under this step's MFMAs
       int tm_r, tn_r;
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
     ttile_coords(tbase + local + ti * nloc, tiles_m, tiles_n, tm, tn);
     ++ti;
     const int m0 = tm * BM + wm * WR, n0 = tn * TBN + wn * 128;
+    PM_TSTAMP(1, ti == 1);
     char* stg = smem + 2 * STAGE + wave * 2048;  // wave-private: no barrier in front of the epilogue
     int el = lane;
     asm volatile("" : "+v"(el));  // the epilogue's lane constants are recomputed per tile, not kept across the K loop (registers)
@@ -393,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
             store_y((bf16x8*)(yb + ylane), ov);
 #endif
         }
+        PM_TSTAMP(2 + q, ti == 1);
       }
     }
 #ifndef PM_TILE_NO_ACC_KILL
@@ -411,6 +429,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
 }
 
 }  // namespace
+
+#if PM_TILE_STAMPS
+extern "C" int pm_debug_tile_stamps(void* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 256 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // Internal entry (called from linear_bf16.hip's dispatcher; arguments already validated there).  mi = 4 or 5.
 int pm_linear_bf16_tile_launch(int mi, const void* x, int64_t ldx, int64_t x_rows_per_batch, int64_t x_batch_stride,
