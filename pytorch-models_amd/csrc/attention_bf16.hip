@@ -266,6 +266,17 @@ _Pragma("unroll")                                                               
 // memory operand: "may alias") behind a vmcnt(0) of its own - the next head's prefetch then never overlaps this head's
 // arithmetic.  Hidden, the completion is ours to count: the vmcnt wait in
 // front of the per-head barrier.  (cdna_hip_programming.md, inline-asm rules: M0 written in the statement that reads it.)
+// a lane's value combined with its partner's 32 lanes away: gfx950's v_permlane32_swap (one vector-ALU instruction; hipcc turns
+// __shfl_xor into ds_bpermute_b32, an LDS round trip)
+__device__ __forceinline__ float ah_max_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float ah_add_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_dst_wave_base) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
@@ -295,7 +306,7 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_dst
 #define PM_AH_KPF 1
 #endif
 #ifndef PM_AH_QLDS
-#define PM_AH_QLDS 0
+#define PM_AH_QLDS 1
 #endif
 #ifndef PM_AH_STAMP_IT
 #define PM_AH_STAMP_IT 5
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
       for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kb][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = ah_max_xor32(mx);
       const float mc = mx * c;
       PM_AH_STAMP(5);
       f32x2 ps2 = {0.f, 0.f};  // two chains for the row sum
@@ -635,15 +646,18 @@ __global__ __launch_bounds__(512) void attn_head_hd64(const bf16* __restrict__ Q
 #endif
       PM_AH_STAMP(6);
       const float ps = ps2[0] + ps2[1];
-      const float inv = 1.0f / (ps + __shfl_xor(ps, 32, 64));
+      const float inv = 1.0f / ah_add_xor32(ps);  // (a + b on both sides: the same bits as ps + shfl_xor(ps))
       // ---- O^T (query on the lane) -> row-major rows through the wave's own 4 KiB: chunk c of query row q at c ^ (q & 7)
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
+          // aligned register pairs spelled out: two packed multiplies and two packed conversions per four values (hipcc's own
+          // pairing took (1, 2) and patched 0 and 3 around it: 13 instructions)
+          const f32x2 lo = f32x2{oacc[db][4 * gq], oacc[db][4 * gq + 1]} * f32x2{inv, inv};
+          const f32x2 hi = f32x2{oacc[db][4 * gq + 2], oacc[db][4 * gq + 3]} * f32x2{inv, inv};
           bf16x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16)(oacc[db][4 * gq + j] * inv);
+          o[0] = (bf16)lo[0]; o[1] = (bf16)lo[1]; o[2] = (bf16)hi[0]; o[3] = (bf16)hi[1];
           *(bf16x4*)(stg + r * 128 + (((db * 4 + gq) ^ (r & 7)) * 16) + hh * 8) = o;
         }
       PM_AH_STAMP(7);
