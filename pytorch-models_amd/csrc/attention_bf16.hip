@@ -256,11 +256,16 @@ _Pragma("unroll")                                                               
 // 4 KiB transposition so that a store instruction writes 8 full 128-byte rows instead of 32 16-byte fragments.
 // Layouts (K image, V image, fragment and transposed reads, S^T / O^T accumulator geometry) are the tiled kernel's.
 // Measured at C2 (B = 256, H = 12, L = 197; tools/attn_bench.py, then in the model): 110 -> 86 us standalone, 92 -> 78 us
-// per layer inside ViT-B/16.  With the arithmetic switched off the kernel streams its 309 MB in 60 us (5.2 TB/s), with
-// the loads switched off it computes for 65 us (vector ALU ~45 % busy, matrix pipe 19 %: SQ counters); together 86 - the
-// per-head barrier drains the CU's load queue once per head.  Tried on top and dropped: waves 4-7 delayed by the QK^T phase
-// (so one wave of a SIMD pair issues MFMAs while the other is in its exponentials): 91 us; keeping the four output stores in
-// flight across the barrier by counting (vmcnt(4)): no change against storing the previous head's rows after the barrier.
+// per layer inside ViT-B/16 (round 2); 82 -> 73 us standalone on one box in round 3 (profiles/r03/attention_head_stamps.txt).
+// With the arithmetic switched off the kernel streams its 309 MB in 60 us (5.2 TB/s), with the loads switched off it computed
+// for 65 us (vector ALU ~45 % busy, matrix pipe 19 %: SQ counters).  Round 3's in-kernel stamps (tools/attn_stamps.py) showed
+// where the rest went - not into waiting for HBM (0.2 us per head) but into REQUESTING: an LDS-DMA piece, a load or a store costs
+// the wave that issues it 100-200 ns in which it issues nothing else, all eight waves did their 15 behind the barrier, and
+// QK^T ran as ds_read / wait / MFMA.  Hence, below: the query-less wave requests every K / V piece (PM_AH_SOLO), the partners of
+// a SIMD make their remaining requests at different times (PM_AH_LATE), queries come as whole rows through the staging area
+// (PM_AH_QLDS), K fragments are read two blocks ahead (PM_AH_KPF).  Tried and dropped: waves 4-7 delayed by the whole QK^T phase
+// (91 us); four output stores kept in flight across the barrier (no change); every request spread between the arithmetic's
+// blocks (no change: the time moves with the requests); wave 7 requesting with 64-bit lane addresses (it became the critical path).
 //
 // LDS-DMA that hipcc does not see.  With the builtin form it orders every later ds_read_b64_tr_b16 (an intrinsic without a
 // memory operand: "may alias") behind a vmcnt(0) of its own - the next head's prefetch then never overlaps this head's
