@@ -28,6 +28,10 @@
 namespace {
 // In-kernel stamps of the epilogue (variant builds only: -DPM_TILE_STAMPS=1; tools/tile_stamps.py): per workgroup, its first tile:
 // slot 0 = the last K step's barrier, 1 = epilogue start, 2 + q = behind block q, 15 = wave 0's view only.
+#ifndef PM_TILE_RESID16  // experiment (tools/build_variant.sh): the residual as two 16-byte requests per block + lane swaps
+#define PM_TILE_RESID16 0  // instead of four 8-byte ones - same results, fc2 half batch 93.5 us against 92.7: not the request count
+#endif
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef PM_TILE_STAMPS
 #define PM_TILE_STAMPS 0
 #endif
@@ -172,10 +176,38 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
       rb_ = (const char*)resid + (int64_t)r0_ * ldr * 2;                                                             \
       ro_ = (uint32_t)(mm_ - r0_) * (uint32_t)(ldr * 2);                                                             \
     }                                                                                                                \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                               \
-      int nn_ = (n0_) + hf_ * 64 + jj * 16 + (fq_) * 4;                                                              \
-      nn_ = nn_ < N ? nn_ : N - 4; /* features beyond N are never stored */                                          \
-      PM_TILE_RESID_LOAD(rv[slot_][jj], rb_ + (uint32_t)(ro_ + (uint32_t)nn_ * 2));                                  \
+    if (PM_TILE_RESID16) {                                                                                           \
+      /* two 16-byte requests instead of four of 8 bytes: lanes fq and fq ^ 1 (16 lanes apart, the same row) fetch the 8    \
+         features they share of subtiles 2 k + (fq & 1); PM_TRESID_UNSWAP trades halves when the block is used */     \
+      _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                                             \
+        int nn_ = (n0_) + hf_ * 64 + (2 * k_ + ((fq_) & 1)) * 16 + ((fq_) & ~1) * 4;                                 \
+        nn_ = nn_ < N - 8 ? nn_ : N - 8; /* features beyond N are never stored */                                    \
+        const bf16x8 l_ = *(const bf16x8*)(rb_ + (uint32_t)(ro_ + (uint32_t)nn_ * 2));                               \
+        rv[slot_][2 * k_] = __builtin_shufflevector(l_, l_, 0, 1, 2, 3);                                             \
+        rv[slot_][2 * k_ + 1] = __builtin_shufflevector(l_, l_, 4, 5, 6, 7);                                         \
+      }                                                                                                              \
+    } else {                                                                                                         \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                             \
+        int nn_ = (n0_) + hf_ * 64 + jj * 16 + (fq_) * 4;                                                            \
+        nn_ = nn_ < N ? nn_ : N - 4; /* features beyond N are never stored */                                        \
+        PM_TILE_RESID_LOAD(rv[slot_][jj], rb_ + (uint32_t)(ro_ + (uint32_t)nn_ * 2));                                \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+  // even rows of 16 lanes (fq even) hold (own, partner's) halves of subtile 2 k, odd rows of subtile 2 k + 1: v_permlane16_swap
+  // trades the odd rows of its first operand with the even rows of its second - afterwards rv[.][2 k] and rv[.][2 k + 1] are
+  // this lane's four features of both subtiles
+#define PM_TRESID_UNSWAP(slot_)                                                                                      \
+  if (PM_TILE_RESID16) {                                                                                             \
+    _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_) {                                                               \
+      u32x2 p_ = __builtin_bit_cast(u32x2, rv[slot_][2 * k_]), q_ = __builtin_bit_cast(u32x2, rv[slot_][2 * k_ + 1]); \
+      _Pragma("unroll") for (int w_ = 0; w_ < 2; ++w_) {                                                             \
+        const auto r_ = __builtin_amdgcn_permlane16_swap(p_[w_], q_[w_], false, false);                              \
+        p_[w_] = r_[0];                                                                                              \
+        q_[w_] = r_[1];                                                                                              \
+      }                                                                                                              \
+      rv[slot_][2 * k_] = __builtin_bit_cast(bf16x4, p_);                                                            \
+      rv[slot_][2 * k_ + 1] = __builtin_bit_cast(bf16x4, q_);                                                        \
     }                                                                                                                \
   }
 
@@ -358,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_tile_kernel(
         const int q = hf * MI + i;
         if constexpr (RES) {
           if (q + RPF < 2 * MI) PM_TLOAD_RESID(q + RPF, (q + RPF) % (RPF + 1), m0, n0, efr, efq);
+          PM_TRESID_UNSWAP(q % (RPF + 1))
         }
         bf16x4 o[4];
 #pragma unroll
