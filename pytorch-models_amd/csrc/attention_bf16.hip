@@ -18,6 +18,17 @@
 #include "common.h"
 
 namespace {
+// a lane's value combined with its partner's 32 lanes away: gfx950's v_permlane32_swap (one vector-ALU instruction; hipcc turns
+// __shfl_xor into ds_bpermute_b32, an LDS round trip)
+__device__ __forceinline__ float ah_max_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float ah_add_xor32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 
 constexpr int KV_TILE = 64;
 constexpr int TILE_B = KV_TILE * 128;  // 8 KiB: 64 rows x 64 bf16
@@ -166,23 +177,28 @@ _Pragma("unroll")                                                               
         sc[kb][i] = v;                                                                                                   \
         mx = fmaxf(mx, v);                                                                                               \
       }                                                                                                                  \
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                              \
+    mx = ah_max_xor32(mx);                                                                                               \
     if (!(MASKED)) mx *= c;                                                                                              \
     const float m_new = fmaxf(m_run, mx);                                                                                \
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                           \
     m_run = m_new;                                                                                                       \
-    float ps = 0.f;                                                                                                      \
+    f32x2 ps2 = {0.f, 0.f};  /* two chains for the row sum: two scores per packed fma / add (the kernel is VALU-bound) */  \
 _Pragma("unroll")                                                                                                        \
     for (int kb = 0; kb < 2; ++kb)                                                                                       \
 _Pragma("unroll")                                                                                                        \
-      for (int i = 0; i < 16; ++i) {                                                                                     \
+      for (int i = 0; i < 16; i += 2) {                                                                                  \
         if (kb == 1 && !kb1) continue;                                                                                   \
         /* mask-free: the scale rides in the exponent's fma, exp2(fma(s, c, -max)) - no multiply per score */            \
-        const float p = __builtin_amdgcn_exp2f((MASKED) ? sc[kb][i] - m_new : fmaf(sc[kb][i], c, -m_new));               \
-        sc[kb][i] = p;                                                                                                   \
-        ps += p;                                                                                                         \
+        const f32x2 s2 = {sc[kb][i], sc[kb][i + 1]};                                                                     \
+        const f32x2 a = (MASKED) ? s2 - f32x2{m_new, m_new} : __builtin_elementwise_fma(s2, f32x2{c, c}, f32x2{-m_new, -m_new}); \
+        f32x2 p;                                                                                                         \
+        p[0] = __builtin_amdgcn_exp2f(a[0]);                                                                             \
+        p[1] = __builtin_amdgcn_exp2f(a[1]);                                                                             \
+        sc[kb][i] = p[0];                                                                                                \
+        sc[kb][i + 1] = p[1];                                                                                            \
+        ps2 += p;                                                                                                        \
       }                                                                                                                  \
-    l_run = fmaf(l_run, alpha, ps);                                                                                      \
+    l_run = fmaf(l_run, alpha, ps2[0] + ps2[1]);                                                                         \
 _Pragma("unroll")                                                                                                        \
     for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }                                           \
     /* ---- O^T += V^T P^T */                                                                                            \
@@ -228,7 +244,7 @@ _Pragma("unroll")                                                               
   for (; t < nT; ++t) { PM_ATT_TILE(true, t & 1) }
 #undef PM_ATT_TILE
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = ah_add_xor32(l_run);
   const float inv = 1.0f / l_tot;
   if (qi < Lq) {
     bf16* op = O + (int64_t)b * osb + (int64_t)qi * ost + h * 64;
@@ -271,17 +287,6 @@ _Pragma("unroll")                                                               
 // memory operand: "may alias") behind a vmcnt(0) of its own - the next head's prefetch then never overlaps this head's
 // arithmetic.  Hidden, the completion is ours to count: the vmcnt wait in
 // front of the per-head barrier.  (cdna_hip_programming.md, inline-asm rules: M0 written in the statement that reads it.)
-// a lane's value combined with its partner's 32 lanes away: gfx950's v_permlane32_swap (one vector-ALU instruction; hipcc turns
-// __shfl_xor into ds_bpermute_b32, an LDS round trip)
-__device__ __forceinline__ float ah_max_xor32(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float ah_add_xor32(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 __device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_dst_wave_base) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);

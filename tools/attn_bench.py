@@ -14,7 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=300)  # a window of tens of ms: see tools/_timing.py
 args = ap.parse_args()
 torch.manual_seed(0)
-for name, B, L, H, causal in (("vit-b/16", 256, 197, 12, False), ("whisper-base enc", 32, 1500, 8, False), ("causal 448", 32, 448, 8, True)):
+for name, B, L, H, causal in (("vit-b/16", 256, 197, 12, False), ("whisper-base enc", 32, 1500, 8, False), ("causal 448", 32, 448, 8, True),
+                              ("vit-l/16 @384 half batch", 128, 576, 16, False)):
     inner = H * 64
     qkv = torch.randn(B, L, 3 * inner, device="cuda").to(torch.bfloat16)
     q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
@@ -28,4 +29,4 @@ for name, B, L, H, causal in (("vit-b/16", 256, 197, 12, False), ("whisper-base 
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / args.iters * 1e3
     fl = 4.0 * B * H * L * L * 64 * (0.5 if causal else 1.0)
-    print(f"{name:18s} B={B} L={L} H={H}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+    print(f"{name:26s} B={B} L={L} H={H}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
