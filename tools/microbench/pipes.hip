@@ -59,6 +59,35 @@ __global__ __launch_bounds__(512) void pipes(const char* roles, int iters, float
   if (s == 12345.678f) sink[0] = s;
 }
 
+// vector-ALU roles only, up to 4 waves per SIMD (1024 threads): does the per-wave issue rate or the pipe bound the loop?
+// A = 32 v_add_f32 (two register operands), F = 32 v_fma_f32 (three), P = 16 v_pk_fma_f32, E = 8 v_exp_f32 (+ 8 v_sub)
+__global__ __launch_bounds__(1024) void valu_waves(const char* roles, int iters, float* sink) {
+  const int wave = threadIdx.x >> 6;
+  const char role = roles[wave];
+  float e[8], f[32];
+  f32x2 p[16];
+  for (int i = 0; i < 8; ++i) e[i] = -1.0f - i * 1e-3f - threadIdx.x * 1e-6f;
+  for (int i = 0; i < 32; ++i) f[i] = 1.0f + i * 1e-3f;
+  for (int i = 0; i < 16; ++i) p[i] = f32x2{1.0f + i, 2.0f + i};
+  const float fa = 0.999f, fb = 1e-3f;
+  if (role != '-') {
+    for (int it = 0; it < iters; ++it) {
+      if (role == 'E') { body_E(e); for (int i = 0; i < 8; ++i) asm volatile("v_sub_f32 %0, 0, %0" : "+v"(e[i])); }
+      if (role == 'F') body_F(f, fa, fb);
+      if (role == 'A') {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fb));
+      }
+      if (role == 'P') body_P(p, f32x2{fa, fa}, f32x2{fb, fb});
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += e[i];
+  for (int i = 0; i < 32; ++i) s += f[i];
+  for (int i = 0; i < 16; ++i) s += p[i][0] + p[i][1];
+  if (s == 12345.678f) sink[0] = s;
+}
+
 int main() {
   const int iters = 20000;
   char* d_roles; float* sink;
@@ -79,5 +108,24 @@ int main() {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("%s   %9.1f   %8.1f\n", c, ms * 1e3, ms * 1e-3 * 2.4e9 / iters);
   }
+  printf("\nvector-ALU roles, 1 .. 4 waves per SIMD (1024-thread workgroup, wave w on SIMD w %% 4):   us   cycles/iteration @2.4 GHz   cycles per instruction and SIMD\n");
+  char* d16; (void)hipMalloc(&d16, 16);
+  for (char r : {'A', 'F', 'P', 'E'})
+    for (int n = 1; n <= 4; ++n) {
+      char cfg[17];
+      for (int w = 0; w < 16; ++w) cfg[w] = w < 4 * n ? r : '-';
+      cfg[16] = 0;
+      (void)hipMemcpy(d16, cfg, 16, hipMemcpyHostToDevice);
+      valu_waves<<<256, 1024>>>(d16, iters, sink);
+      (void)hipDeviceSynchronize();
+      (void)hipEventRecord(e0);
+      valu_waves<<<256, 1024>>>(d16, iters, sink);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      const double cyc = ms * 1e-3 * 2.4e9 / iters;
+      const int per_iter = r == 'P' ? 16 : r == 'E' ? 16 : 32;
+      printf("%s   %9.1f   %8.1f   %6.2f\n", cfg, ms * 1e3, cyc, cyc / (per_iter * n));
+    }
   return 0;
 }
